@@ -1,0 +1,194 @@
+"""Synthetic parameter batches for the batched NMPC solver.
+
+Every instance is one flat parameter vector ``p`` in exactly the layout the reference's tracker assembles
+(``/root/reference/src/pkg_mpc_tracker/trajectory_tracker.py:315-317``; symbol order
+``solver_build/mpc_builder.py:47-60``)::
+
+    u_m1(2) s_0(3) s_N(3) q(10) r_s(3N) r_v(N) c_0(3*Nother) c(3*N*Nother) o_s(12*Nstc) o_d(6*(N+1)*Ndyn)
+    q_stc(N) q_dyn(N)
+
+The generator is deterministic (``numpy.random.default_rng(seed)``) and vectorised, so the same batch can be
+regenerated on the GPU box and in the authoring container.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass(frozen=True)
+class ParamLayout:
+    """Offsets of the 12 parameter blocks."""
+    N: int = 20
+    Nother: int = 10
+    Nstc: int = 10
+    Ndyn: int = 15
+
+    @property
+    def um1(self):
+        return 0
+
+    @property
+    def s0(self):
+        return 2
+
+    @property
+    def sN(self):
+        return 5
+
+    @property
+    def q(self):
+        return 8
+
+    @property
+    def rs(self):
+        return 18
+
+    @property
+    def rv(self):
+        return self.rs + 3 * self.N
+
+    @property
+    def c0(self):
+        return self.rv + self.N
+
+    @property
+    def c(self):
+        return self.c0 + 3 * self.Nother
+
+    @property
+    def os(self):
+        return self.c + 3 * self.N * self.Nother
+
+    @property
+    def od(self):
+        return self.os + 12 * self.Nstc
+
+    @property
+    def qstc(self):
+        return self.od + 6 * (self.N + 1) * self.Ndyn
+
+    @property
+    def qdyn(self):
+        return self.qstc + self.N
+
+    @property
+    def np_(self):
+        return self.qdyn + self.N
+
+
+# work-mode tuning parameters of the shipped yaml files (trajectory_tracker.py:138-139 + config/mpc_*.yaml:33-43)
+WORK_MODE_Q = (0.0, 10.0, 0.0, 0.0, 0.0, 0.0, 0.0, 100.0, 10.0, 20.0)
+
+
+def box_halfspaces(cx, cy, hx, hy):
+    """(b, a0, a1) rows of an axis-aligned box, in the convention of
+    ``pkg_mpc_tracker/utils_geo.py:35-62`` (A (p - centre) <= 1  <=>  b - a0 x - a1 y >= 0)."""
+    a0 = np.stack([1.0 / hx, -1.0 / hx, np.zeros_like(hx), np.zeros_like(hx)], axis=-1)
+    a1 = np.stack([np.zeros_like(hy), np.zeros_like(hy), 1.0 / hy, -1.0 / hy], axis=-1)
+    b = a0 * cx[..., None] + a1 * cy[..., None] + 1.0
+    return b, a0, a1
+
+
+def make_batch(B: int, layout: ParamLayout = ParamLayout(), seed: int = 0, n_ped: int = 2, n_hyp: int = 5,
+               ts: float = 0.2, base_speed: float = 1.2, n_boxes: int = 4, dtype=np.float64) -> np.ndarray:
+    """SURVEY.md 8d synthetic generator. Returns ``P[B, np]``.
+
+    Robot: s0 xy ~ U(-10,10)^2, theta ~ U(-pi,pi); previous action u_m1 = (U(0,1.2), U(-0.3,0.3)).
+    Reference: straight polyline from s0 along heading theta + U(-0.5,0.5), one point every ts*base_speed
+    (what ``TrajectoryTracker.get_ref_traj`` produces in 'work' mode); r_v = base_speed.
+    Pedestrians: start 3-8 m ahead, +-2 m lateral, walk toward the robot at 1.0-1.5 m/s; hypothesis h fans
+    out by (h - (n_hyp-1)/2) * 0.15 rad; ellipse radii 0.2 + 0.05 t, angle 0, alpha 1
+    (``main_base.py:293-302``); remaining Ndyn slots zero (``interfaces/mpc_interface.py:82-88``).
+    Static: ``n_boxes`` axis-aligned 1 x 2 m boxes within 6 m of the robot; remaining slots zero.
+    Other robots: zero (reference default, ``trajectory_tracker.py:295-296``).
+    """
+    L = layout
+    N = L.N
+    assert n_ped * n_hyp <= L.Ndyn and n_boxes <= L.Nstc
+    rng = np.random.default_rng(seed)
+    P = np.zeros((B, L.np_), dtype=np.float64)
+
+    xy = rng.uniform(-10.0, 10.0, size=(B, 2))
+    th = rng.uniform(-np.pi, np.pi, size=B)
+    P[:, L.um1] = rng.uniform(0.0, 1.2, size=B)
+    P[:, L.um1 + 1] = rng.uniform(-0.3, 0.3, size=B)
+    P[:, L.s0:L.s0 + 2] = xy
+    P[:, L.s0 + 2] = th
+    P[:, L.q:L.q + 10] = np.asarray(WORK_MODE_Q)
+
+    # reference states: N rows (x, y, heading)
+    hd = th + rng.uniform(-0.5, 0.5, size=B)
+    d = np.stack([np.cos(hd), np.sin(hd)], axis=1)
+    steps = (np.arange(1, N + 1) * ts * base_speed)[None, :, None]
+    ref_xy = xy[:, None, :] + steps * d[:, None, :]
+    rs = np.concatenate([ref_xy, np.broadcast_to(hd[:, None, None], (B, N, 1))], axis=2)
+    P[:, L.rs:L.rs + 3 * N] = rs.reshape(B, 3 * N)
+    P[:, L.sN:L.sN + 3] = rs[:, -1, :]
+    P[:, L.rv:L.rv + N] = base_speed
+
+    # static boxes -> half-space rows (b0..3, a0_0..3, a1_0..3)
+    if n_boxes:
+        ang = rng.uniform(-np.pi, np.pi, size=(B, n_boxes))
+        rad = rng.uniform(1.5, 6.0, size=(B, n_boxes))
+        bcx = xy[:, 0:1] + rad * np.cos(ang)
+        bcy = xy[:, 1:2] + rad * np.sin(ang)
+        tall = rng.random(size=(B, n_boxes)) < 0.5
+        hx = np.where(tall, 0.5, 1.0)
+        hy = np.where(tall, 1.0, 0.5)
+        b, a0, a1 = box_halfspaces(bcx, bcy, hx, hy)
+        os_ = np.concatenate([b, a0, a1], axis=-1)  # [B, n_boxes, 12]
+        P[:, L.os:L.os + 12 * n_boxes] = os_.reshape(B, 12 * n_boxes)
+
+    # pedestrians x hypotheses -> ellipses [Ndyn][N+1][6]
+    od = np.zeros((B, L.Ndyn, N + 1, 6))
+    if n_ped:
+        fwd = np.stack([np.cos(th), np.sin(th)], axis=1)
+        lat = np.stack([-np.sin(th), np.cos(th)], axis=1)
+        ahead = rng.uniform(3.0, 8.0, size=(B, n_ped))
+        side = rng.uniform(-2.0, 2.0, size=(B, n_ped))
+        start = xy[:, None, :] + ahead[..., None] * fwd[:, None, :] + side[..., None] * lat[:, None, :]
+        speed = rng.uniform(1.0, 1.5, size=(B, n_ped))
+        to_robot = xy[:, None, :] - start
+        base_ang = np.arctan2(to_robot[..., 1], to_robot[..., 0])
+        t = np.arange(N + 1)[None, None, None, :]
+        fan = (np.arange(n_hyp) - (n_hyp - 1) / 2.0) * 0.15
+        a = base_ang[:, :, None] + fan[None, None, :]           # [B, ped, hyp]
+        dist = speed[:, :, None, None] * t * ts                  # [B, ped, 1, T]
+        cxs = start[:, :, None, None, 0] + dist * np.cos(a)[..., None]
+        cys = start[:, :, None, None, 1] + dist * np.sin(a)[..., None]
+        r = 0.2 + 0.05 * np.arange(N + 1)
+        k = n_ped * n_hyp
+        od[:, :k, :, 0] = cxs.reshape(B, k, N + 1)
+        od[:, :k, :, 1] = cys.reshape(B, k, N + 1)
+        od[:, :k, :, 2] = r
+        od[:, :k, :, 3] = r
+        od[:, :k, :, 4] = 0.0
+        od[:, :k, :, 5] = 1.0
+    P[:, L.od:L.od + 6 * (N + 1) * L.Ndyn] = od.reshape(B, -1)
+
+    P[:, L.qstc:L.qstc + N] = 10.0
+    P[:, L.qdyn:L.qdyn + N] = 10.0
+    return P.astype(dtype)
+
+
+# BASELINE.json configs[1..4] -> (layout, generator kwargs, batch)
+BENCH_CONFIGS = {
+    # batch=1024 random init states, N=20, 2 obstacles x 5 WTA hypotheses, fp32
+    "cfg1_b1024_n20_2x5": dict(layout=ParamLayout(20, 10, 10, 15), B=1024, seed=0, n_ped=2, n_hyp=5),
+    # batch=65536 main_eva scenarios, N=20, 4 obs x 10 hypotheses
+    "cfg2_b65536_n20_4x10": dict(layout=ParamLayout(20, 10, 10, 40), B=65536, seed=1, n_ped=4, n_hyp=10),
+    # long horizon N=40, 8 obs x 20 hypotheses, batch=8192
+    "cfg4_b8192_n40_8x20": dict(layout=ParamLayout(40, 10, 10, 160), B=8192, seed=5, n_ped=8, n_hyp=20),
+}
+
+
+def make_config_batch(name: str, B: int | None = None, seed: int | None = None, dtype=np.float64):
+    cfg = dict(BENCH_CONFIGS[name])
+    if B is not None:
+        cfg["B"] = B
+    if seed is not None:
+        cfg["seed"] = seed
+    layout = cfg.pop("layout")
+    return layout, make_batch(layout=layout, dtype=dtype, **cfg)

@@ -1,0 +1,349 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE'S OWN PYTHON CODE.
+
+Runs only in the authoring container (needs /root/reference); the produced ``*.npz`` / ``*.json`` files are
+data (inputs + expected outputs) and are what travels to the GPU box. ``casadi`` / ``opengen`` are absent
+from the image, so the reference modules are imported on top of the numeric stand-in in
+``_numeric_casadi.py`` (matrix plumbing only, see its docstring).
+
+Fixtures written:
+  known_answers.json   outputs of the reference's mpc_helper / mpc_cost functions on the inputs of the reference's
+                       own unit tests (src/tests/test_mpc_builder.py:16-253), next to the expected values those
+                       tests assert.
+  problem_n20.npz      f, F1, F2 from MpcModule.build(unicycle_model, test=True) (mpc_builder.py:28-201) on
+                       config/mpc_fast.yaml for random (u, p): U, P, f, F1, F2 (+ finite-difference grad f).
+  problem_small.npz    same for a reduced-dimension yaml (N=6, Nother=3, Nstc=2, Ndyn=4).
+  motion_model.npz     unicycle_model RK4 (basic_motion_model/motion_model.py:141-163) on random states/actions.
+  tracker_harness.json parameter lists / return values of TrajectoryTracker.run_step
+                       (pkg_mpc_tracker/trajectory_tracker.py:273-383) driven by a scripted fake solver.
+
+Usage:  python tests/golden/make_golden.py
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(REF, "src"))
+
+import _numeric_casadi as nc  # noqa: E402
+
+cs, og = nc.install()
+
+with contextlib.redirect_stdout(io.StringIO()):
+    from basic_motion_model import motion_model  # noqa: E402
+    from configs import CircularRobotSpecification, MpcConfiguration  # noqa: E402
+    from pkg_mpc_tracker.solver_build import mpc_builder, mpc_cost, mpc_helper  # noqa: E402
+
+SX = nc.SX
+
+
+def _f(x):
+    return np.asarray(x.a, dtype=float).tolist()
+
+
+# ---------------------------------------------------------------------------------------------------------
+def known_answers():
+    """Inputs copied as DATA from the reference's unit tests; outputs computed by the reference's functions."""
+    out = {}
+    out["dist_to_points_square"] = dict(
+        got=_f(mpc_helper.dist_to_points_square(SX([[0, 0]]), SX([[1, 0], [2, 0]]))), expected=[[1, 4]])
+    out["dist_to_lineseg_1"] = dict(
+        got=_f(mpc_helper.dist_to_lineseg(SX([[1, 2]]), SX([[3, 2], [3, 0]]))), expected=[[2.0]])
+    out["dist_to_lineseg_2"] = dict(
+        got=_f(mpc_helper.dist_to_lineseg(SX([[1, 2]]), SX([[3, 1], [3, 0]]))), expected=[[5 ** 0.5]])
+    ell = [SX([[1, 1]]), SX([[2, 4]]), SX([[1, 1]]), SX([[1, 1]]), SX([[0, 0]])]
+    out["inside_ellipses"] = dict(got=_f(mpc_helper.inside_ellipses(SX([[1, 2]]), ell)), expected=[[1, -3]])
+    poly1 = dict(b=SX([[0, 2, 1, 3]]), a0=SX([[-1, 1, 0, 0]]), a1=SX([[0, 0, -1, 1]]))
+    poly2 = dict(b=SX([[0, 1, 0, 1]]), a0=SX([[-1, 1, 0, 0]]), a1=SX([[0, 0, -1, 1]]))
+    out["inside_cvx_polygon_1"] = dict(got=_f(mpc_helper.inside_cvx_polygon(SX([[1, 2]]), **poly1)), expected=[[3]])
+    out["inside_cvx_polygon_2"] = dict(got=_f(mpc_helper.inside_cvx_polygon(SX([[1, 2]]), **poly2)), expected=[[0]])
+    out["outside_cvx_polygon_1"] = dict(got=_f(mpc_helper.outside_cvx_polygon(SX([[1, 2]]), **poly1)), expected=[[0]])
+    out["outside_cvx_polygon_2"] = dict(got=_f(mpc_helper.outside_cvx_polygon(SX([[1, 2]]), **poly2)), expected=[[1]])
+    out["cost_inside_cvx_polygon"] = dict(
+        got=_f(mpc_cost.cost_inside_cvx_polygon(SX([[1, 2]]), weight=2, **poly1)), expected=[[18]])
+    out["cost_inside_ellipses"] = dict(got=_f(mpc_cost.cost_inside_ellipses(SX([[1, 2]]), ell)), expected=[[1, 0]])
+    out["cost_control_actions"] = dict(
+        got=_f(mpc_cost.cost_control_actions(SX([[1, 2, 3]]), SX([[2, 1, 1]]))), expected=[[15]])
+    out["cost_control_jerks"] = dict(
+        got=_f(mpc_cost.cost_control_jerks(SX([[1, 2, 3]]), SX([[0, 1, 1]]), 2)), expected=[[12]])
+    out["cost_fleet_collision_1"] = dict(
+        got=_f(mpc_cost.cost_fleet_collision(SX([[1, 2]]), SX([[0, 0], [2, 0]]), 2, 2)), expected=[[0]])
+    out["cost_fleet_collision_2"] = dict(
+        got=_f(mpc_cost.cost_fleet_collision(SX([[1, 2]]), SX([[0, 1], [2, 0]]), 2, 2)), expected=[[4]])
+    out["cost_refvalue_deviation"] = dict(got=_f(mpc_cost.cost_refvalue_deviation(SX([1]), SX([0]), 2)), expected=[[2]])
+    out["cost_refstate_deviation"] = dict(
+        got=_f(mpc_cost.cost_refstate_deviation(SX([[1, 2]]), SX([[0, 0]]), 2)), expected=[[10]])
+    out["cost_refpath_deviation"] = dict(
+        got=_f(mpc_cost.cost_refpath_deviation(SX([[1, 2]]), SX([[0, 0], [1, 0], [3, 2]]), 0.5)), expected=[[1.0]])
+    out["cost_refpoint_detach"] = dict(
+        got=_f(mpc_cost.cost_refpoint_detach(SX([[1, 2]]), SX([[1, 0]]), 1, 2)), expected=[[2]])
+    for k, v in out.items():
+        assert np.allclose(np.asarray(v["got"]).ravel(), np.asarray(v["expected"]).ravel(), atol=1e-3), (k, v)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+BLOCKS = ("u_m1", "s_0", "s_N", "q", "r_s", "r_v", "c_0", "c", "os", "od", "qstc", "qdyn")
+
+
+def split_params(p, N, Nother, Nstc, Ndyn):
+    sizes = (2, 3, 3, 10, 3 * N, N, 3 * Nother, 3 * N * Nother, 12 * Nstc, 6 * (N + 1) * Ndyn, N, N)
+    out, o = {}, 0
+    for name, s in zip(BLOCKS, sizes):
+        out[name] = p[o:o + s]
+        o += s
+    assert o == p.size, (o, p.size)
+    return out
+
+
+def reference_eval(cfg_path, u, p):
+    """f, F1, F2 for numbers (u, p), computed by the reference's MpcModule.build(..., test=True)."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = MpcConfiguration.from_yaml(cfg_path)
+        rob = CircularRobotSpecification.from_yaml(cfg_path)
+    nc.SYM_VALUES.clear()
+    nc.SYM_VALUES["u"] = u
+    nc.SYM_VALUES.update(split_params(p, cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs))
+    with contextlib.redirect_stdout(io.StringIO()):
+        rc = mpc_builder.MpcModule(cfg, rob).build(motion_model.unicycle_model, test=True)
+    assert rc == 1
+    cap = nc.CAPTURED
+    z = np.asarray(cap["p"].a).ravel(order="F")
+    assert np.array_equal(z, p), "parameter vector order differs from the tracker's"
+    f = float(np.asarray(cap["cost"].a).ravel()[0])
+    F1 = np.asarray(cap["F1"].a).ravel(order="F").copy()
+    F2 = np.asarray(cap["F2"].a).ravel(order="F").copy()
+    meta = dict(umin=cap["bounds"].xmin, umax=cap["bounds"].xmax, cmin=cap["set_c"].xmin, cmax=cap["set_c"].xmax,
+                solver_config=[(n, list(a)) for n, a, _ in cap["solver_config_calls"]],
+                optimizer_name=cap["meta_calls"][0][1][0], np=int(z.size), n1=int(F1.size), n2=int(F2.size))
+    return f, F1, F2, meta
+
+
+def random_instance(rng, N, Nother, Nstc, Ndyn, ts, lo, hi):
+    """A (u, p) pair that exercises every cost term: robot driven through obstacles, active fleet terms,
+    rotated ellipses, all weights non-zero."""
+    u = np.empty(2 * N)
+    u[0::2] = rng.uniform(lo[0], hi[0], N)
+    u[1::2] = rng.uniform(lo[1], hi[1], N)
+    s0 = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-np.pi, np.pi)])
+    # nominal rollout to know where the robot goes (plain numpy use of the reference's motion model)
+    traj = [s0]
+    for k in range(N):
+        traj.append(motion_model.unicycle_model(traj[-1], u[2 * k:2 * k + 2], ts))
+    traj = np.array(traj)
+    u_m1 = np.array([rng.uniform(0, 1.2), rng.uniform(-0.3, 0.3)])
+    q = rng.uniform(0.1, 2.0, 10) * np.array([1, 10, 1, 1, 1, 5, 5, 100, 10, 20])
+    hd = s0[2] + rng.uniform(-0.5, 0.5)
+    ref = s0[None, :2] + (np.arange(1, N + 1) * ts * 1.2)[:, None] * np.array([np.cos(hd), np.sin(hd)])[None]
+    if rng.random() < 0.3:   # a bent reference path, padded at the end like get_ref_states does
+        bend = N // 2
+        hd2 = hd + rng.uniform(-1.2, 1.2)
+        ref[bend:] = ref[bend - 1] + (np.arange(1, N - bend + 1) * ts * 1.2)[:, None] * np.array(
+            [np.cos(hd2), np.sin(hd2)])[None]
+        ref[-2:] = ref[-3]
+    r_s = np.concatenate([ref, np.full((N, 1), hd)], axis=1).ravel()
+    s_N = r_s[-3:].copy()
+    r_v = rng.uniform(0.3, 1.5, N)
+    # other robots: some exactly on the robot's track, some far, some zero
+    c_0 = np.zeros((Nother, 3))
+    c = np.zeros((Nother, N, 3))
+    for j in range(Nother):
+        mode = rng.integers(0, 3)
+        if mode == 0:
+            continue
+        kk = rng.integers(0, N + 1)
+        off = rng.normal(0, 0.3 if mode == 1 else 3.0, 2)
+        c_0[j, :2] = traj[kk, :2] + off
+        c[j, :, :2] = traj[1:, :2][::-1] + rng.normal(0, 0.3 if mode == 1 else 3.0, (N, 2))
+        c_0[j, 2] = rng.uniform(-3, 3)
+        c[j, :, 2] = rng.uniform(-3, 3, N)
+    # static polygons: boxes (rotated) around points of the track, some slots zero
+    o_s = np.zeros((Nstc, 12))
+    for i in range(Nstc):
+        if rng.random() < 0.3:
+            continue
+        kk = rng.integers(0, N + 1)
+        ctr = traj[kk, :2] + rng.normal(0, 0.8, 2)
+        hx, hy = rng.uniform(0.3, 1.5, 2)
+        ang = rng.uniform(-np.pi, np.pi)
+        nrm = np.array([[np.cos(ang), np.sin(ang)], [-np.cos(ang), -np.sin(ang)],
+                        [-np.sin(ang), np.cos(ang)], [np.sin(ang), -np.cos(ang)]])
+        A = nrm / np.array([hx, hx, hy, hy])[:, None]
+        b = A @ ctr + 1.0
+        o_s[i] = np.concatenate([b, A[:, 0], A[:, 1]])
+    # dynamic obstacles: ellipses following / crossing the track
+    o_d = np.zeros((Ndyn, N + 1, 6))
+    for j in range(Ndyn):
+        mode = rng.integers(0, 4)
+        if mode == 0:
+            continue  # zero-padded slot (alpha = 0 too), as MpcInterface.get_dyn_constraints leaves it
+        off = rng.normal(0, 0.25 if mode == 1 else 1.5, 2)
+        o_d[j, :, :2] = traj[:, :2] + off + rng.normal(0, 0.1, (N + 1, 2))
+        o_d[j, :, 2] = rng.uniform(0.1, 0.8) + 0.03 * np.arange(N + 1)
+        o_d[j, :, 3] = rng.uniform(0.1, 0.8) + 0.03 * np.arange(N + 1)
+        o_d[j, :, 4] = rng.uniform(-np.pi, np.pi, N + 1)
+        o_d[j, :, 5] = rng.uniform(0.2, 1.5)
+    q_stc = rng.uniform(1, 20, N)
+    q_dyn = rng.uniform(1, 20, N)
+    p = np.concatenate([u_m1, s0, s_N, q, r_s, r_v, c_0.ravel(), c.ravel(), o_s.ravel(), o_d.ravel(), q_stc, q_dyn])
+    return u, p
+
+
+def problem_fixture(cfg_path, K, seed, fd=True):
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = MpcConfiguration.from_yaml(cfg_path)
+        rob = CircularRobotSpecification.from_yaml(cfg_path)
+    rng = np.random.default_rng(seed)
+    N = cfg.N_hor
+    lo, hi = (rob.lin_vel_min, -rob.ang_vel_max), (rob.lin_vel_max, rob.ang_vel_max)
+    U, P, F, F1s, F2s, G = [], [], [], [], [], []
+    meta = None
+    for _ in range(K):
+        u, p = random_instance(rng, N, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs, cfg.ts, lo, hi)
+        f, F1, F2, meta = reference_eval(cfg_path, u, p)
+        U.append(u), P.append(p), F.append(f), F1s.append(F1), F2s.append(F2)
+        if fd:  # central finite differences of the REFERENCE's f (checks the hand-written adjoint)
+            g = np.zeros_like(u)
+            for i in range(u.size):
+                h = 1e-6
+                up, um = u.copy(), u.copy()
+                up[i] += h
+                um[i] -= h
+                g[i] = (reference_eval(cfg_path, up, p)[0] - reference_eval(cfg_path, um, p)[0]) / (2 * h)
+            G.append(g)
+    out = dict(U=np.array(U), P=np.array(P), f=np.array(F), F1=np.array(F1s), F2=np.array(F2s),
+               dims=np.array([N, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs]),
+               robot=np.array([cfg.ts, rob.lin_vel_min, rob.lin_vel_max, rob.ang_vel_max, rob.lin_acc_min,
+                               rob.lin_acc_max, rob.ang_acc_max, rob.vehicle_width, rob.vehicle_margin,
+                               rob.social_margin]),
+               umin=np.array(meta["umin"]), umax=np.array(meta["umax"]),
+               cmin=np.array(meta["cmin"]), cmax=np.array(meta["cmax"]))
+    if fd:
+        out["grad_f_fd"] = np.array(G)
+    return out, meta
+
+
+def motion_model_fixture(seed=3, K=64):
+    rng = np.random.default_rng(seed)
+    S = rng.uniform(-4, 4, (K, 3))
+    A = np.stack([rng.uniform(-0.5, 1.5, K), rng.uniform(-0.5, 0.5, K)], axis=1)
+    ts = 0.2
+    out = np.array([motion_model.unicycle_model(S[i], A[i], ts) for i in range(K)])
+    return dict(S=S, A=A, ts=np.array(ts), S_next=out)
+
+
+# ---------------------------------------------------------------------------------------------------------
+def tracker_harness():
+    """Drive the reference's TrajectoryTracker with a scripted fake solver and record what it sends/returns."""
+    solver_dir = tempfile.mkdtemp(prefix="fake_mpc_solver_")
+    os.makedirs(os.path.join(solver_dir, "mpc_solver", "navi_fast"))
+    with open(os.path.join(solver_dir, "mpc_solver", "navi_fast", "navi_fast.py"), "w") as fh:
+        fh.write(
+            "import types\n"
+            "CALLS = []\n"
+            "class _S:\n"
+            "    def run(self, p, initial_guess=None, initial_lagrange_multipliers=None, initial_penalty=None):\n"
+            "        CALLS.append(dict(p=list(map(float, p)), initial_guess=initial_guess,\n"
+            "                          initial_lagrange_multipliers=initial_lagrange_multipliers,\n"
+            "                          initial_penalty=initial_penalty))\n"
+            "        n = len(CALLS)\n"
+            "        u = []\n"
+            "        for k in range(20):\n"
+            "            u += [0.5 + 0.02 * k + 0.1 * n, 0.1 - 0.01 * k]\n"
+            "        return types.SimpleNamespace(solution=u, cost=12.5 * n, exit_status='Converged',\n"
+            "                                     solve_time_ms=1.25)\n"
+            "def solver():\n"
+            "    return _S()\n")
+    cwd = os.getcwd()
+    os.chdir(solver_dir)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            from pkg_mpc_tracker.trajectory_tracker import TrajectoryTracker
+            cfg_path = os.path.join(REF, "config", "mpc_fast.yaml")
+            cfg = MpcConfiguration.from_yaml(cfg_path)
+            rob = CircularRobotSpecification.from_yaml(cfg_path)
+            tr = TrajectoryTracker(cfg, rob, verbose=False)
+        fake = sys.modules["navi_fast"]
+        tr.load_motion_model(motion_model.UnicycleModel(rob.ts))
+        start = np.array([0.0, 0.0, 0.0])
+        path = [(5.0, 0.0), (5.0, 3.0)]
+        tr.load_init_states(start, np.array([5.0, 3.0, 1.57]))
+        tr.set_work_mode("work")
+        tr.set_ref_trajectory(path)
+        rec = dict(ref_traj=[list(map(float, r)) for r in tr.ref_traj], steps=[])
+        rng = np.random.default_rng(11)
+        for step in range(4):
+            stc = rng.uniform(-1, 1, cfg.Nstcobs * cfg.nstcobs).tolist() if step % 2 == 0 else None
+            dyn = rng.uniform(-1, 1, cfg.Ndynobs * cfg.ndynobs * (cfg.N_hor + 1)).tolist() if step < 3 else None
+            if step == 3:   # teleport near the goal to trigger the speed-reference branch (:305-310)
+                tr.set_current_state(np.array([4.9, 2.6, 1.5]))
+            state_in = tr.state.copy()
+            actions, pred_states, ref_states, cost = tr.run_step(stc, dyn, mode="work")
+            call = fake.CALLS[-1]
+            rec["steps"].append(dict(
+                state_in=state_in.tolist(), stc=stc, dyn=dyn, params=call["p"],
+                kwargs_none=[call["initial_guess"] is None, call["initial_lagrange_multipliers"] is None,
+                             call["initial_penalty"] is None],
+                actions=[a.tolist() for a in actions], pred_states=[s.tolist() for s in pred_states],
+                ref_states=np.asarray(ref_states).tolist(), cost=float(cost), state_out=tr.state.tolist(),
+                idx_ref_traj=int(tr.idx_ref_traj), base_speed=float(tr.base_speed)))
+        rec["past_actions"] = [a.tolist() for a in tr.past_actions]
+        rec["past_states"] = [s.tolist() for s in tr.past_states]
+        rec["solver_time_timelist"] = list(map(float, tr.solver_time_timelist))
+        rec["cost_timelist"] = list(map(float, tr.cost_timelist))
+        # static helpers
+        rec["get_ref_traj_case"] = dict(
+            ts=0.2, path=[[1.0, 0.0], [1.0, 2.0], [3.0, 2.0]], state=[0.0, 0.0, 0.0], speed=0.9,
+            out=[list(map(float, r)) for r in
+                 TrajectoryTracker.get_ref_traj(0.2, [(1.0, 0.0), (1.0, 2.0), (3.0, 2.0)], (0.0, 0.0, 0.0), 0.9)])
+    finally:
+        os.chdir(cwd)
+    return rec
+
+
+def main():
+    ka = known_answers()
+    with open(os.path.join(HERE, "known_answers.json"), "w") as fh:
+        json.dump(ka, fh, indent=1)
+    print("known_answers.json:", len(ka), "cases (all match the values asserted by the reference's tests)")
+
+    fx, meta = problem_fixture(os.path.join(REF, "config", "mpc_fast.yaml"), K=24, seed=20241016)
+    np.savez_compressed(os.path.join(HERE, "problem_n20.npz"), **fx)
+    print("problem_n20.npz:", fx["P"].shape, "np/n1/n2 =", meta["np"], meta["n1"], meta["n2"],
+          "| f range", fx["f"].min(), fx["f"].max(), "| F2>0 in", int((fx["F2"] > 0).any(axis=1).sum()), "cases")
+    with open(os.path.join(HERE, "problem_meta.json"), "w") as fh:
+        json.dump(meta, fh, indent=1)
+
+    with open(os.path.join(REF, "config", "mpc_fast.yaml")) as fh:
+        y = yaml.safe_load(fh)
+    y.update(N_hor=6, Nother=3, Nstcobs=2, Ndynobs=4, optimizer_name="navi_small")
+    tmp = os.path.join(tempfile.mkdtemp(), "mpc_small.yaml")
+    with open(tmp, "w") as fh:
+        yaml.safe_dump(y, fh)
+    fx2, meta2 = problem_fixture(tmp, K=12, seed=7)
+    np.savez_compressed(os.path.join(HERE, "problem_small.npz"), **fx2)
+    print("problem_small.npz:", fx2["P"].shape, "np/n1/n2 =", meta2["np"], meta2["n1"], meta2["n2"])
+
+    np.savez_compressed(os.path.join(HERE, "motion_model.npz"), **motion_model_fixture())
+    print("motion_model.npz written")
+
+    th = tracker_harness()
+    with open(os.path.join(HERE, "tracker_harness.json"), "w") as fh:
+        json.dump(th, fh)
+    print("tracker_harness.json:", len(th["steps"]), "steps, len(p) =", len(th["steps"][0]["params"]))
+
+
+if __name__ == "__main__":
+    main()
