@@ -1,0 +1,24 @@
+"""MI355X-native batched NMPC solver: drop-in for the OpEn/PANOC solver of DyObAv-MPCnWTA-Warehouse.
+
+Host side (Python, mirrors the reference's interface for the solve path only):
+
+* :mod:`.configs`            -- ``MpcConfiguration`` / ``CircularRobotSpecification`` from the unchanged yaml keys
+                                (reference ``src/configs.py:86-103,140-176``)
+* :mod:`.solver`             -- ``solver().run(p, ...)`` object of the generated module (``trajectory_tracker.py:13-15,
+                                54-66, 362``) and the batched front end ``BatchSolver``
+* :mod:`.trajectory_tracker` -- ``TrajectoryTracker.run_step`` (``trajectory_tracker.py:18-416``)
+* :mod:`.solver_build`       -- analogue of ``src/solver_build.py``: compiles the HIP library and writes the
+                                ``mpc_solver/<optimizer_name>/`` module the reference imports
+* :mod:`.scenarios`          -- synthetic parameter batches of BASELINE.json's configurations
+* :mod:`.sharding`           -- one process per GPU, contiguous batch shards, RCCL gather of the results
+
+Device side: ``csrc/`` (hand-written HIP for gfx950) behind the C ABI of ``include/nmpc_hip.h``.
+Import of this package never touches the GPU; the library is loaded on first use.
+"""
+from . import scenarios  # noqa: F401
+from ._capi import (EXIT_STATUS_NAMES, EXPORTED_SYMBOLS, Handle, NmpcConfigStruct, NmpcError,  # noqa: F401
+                    default_config_struct, library_path, load_library)
+from .build import build as build_library  # noqa: F401
+
+__all__ = ["scenarios", "Handle", "NmpcConfigStruct", "NmpcError", "default_config_struct", "load_library",
+           "library_path", "build_library", "EXIT_STATUS_NAMES", "EXPORTED_SYMBOLS"]

@@ -1,0 +1,217 @@
+"""ctypes binding of ``libnmpc_hip.so`` (C ABI declared in ``include/nmpc_hip.h``).
+
+This is the only place the Python host code touches native code. There is deliberately no fallback: if the
+library is missing or no HIP device is visible every entry point raises -- results never come from a CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import build as _build
+
+EXIT_STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotFiniteComputation")
+ABI_VERSION = 1
+
+
+class NmpcError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libnmpc_hip error {code}: {msg}")
+        self.code = code
+
+
+class NmpcConfigStruct(C.Structure):
+    """Mirror of ``struct nmpc_config``."""
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device_id", C.c_int32),
+        ("N_hor", C.c_int32), ("Nother", C.c_int32), ("Nstcobs", C.c_int32), ("Ndynobs", C.c_int32),
+        ("ts", C.c_double),
+        ("lin_vel_min", C.c_double), ("lin_vel_max", C.c_double), ("ang_vel_max", C.c_double),
+        ("lin_acc_min", C.c_double), ("lin_acc_max", C.c_double), ("ang_acc_max", C.c_double),
+        ("vehicle_width", C.c_double), ("vehicle_margin", C.c_double), ("social_margin", C.c_double),
+        ("tolerance", C.c_double), ("initial_tolerance", C.c_double), ("delta_tolerance", C.c_double),
+        ("max_outer_iterations", C.c_int32), ("max_inner_iterations", C.c_int32),
+        ("lbfgs_memory", C.c_int32), ("reserved0", C.c_int32),
+        ("initial_penalty", C.c_double), ("penalty_update_factor", C.c_double),
+        ("inner_tolerance_update_factor", C.c_double), ("sufficient_decrease_coeff", C.c_double),
+        ("lip_eps_f64", C.c_double), ("lip_delta_f64", C.c_double),
+        ("lip_eps_f32", C.c_double), ("lip_delta_f32", C.c_double),
+        ("cbfgs_alpha", C.c_double), ("cbfgs_epsilon", C.c_double), ("sy_epsilon", C.c_double),
+    ]
+
+
+# every symbol include/nmpc_hip.h declares (checked by the CPU test-suite against the built library)
+EXPORTED_SYMBOLS = (
+    "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_param_len", "nmpc_set_stream",
+    "nmpc_solve_batch_f32", "nmpc_solve_batch_f64", "nmpc_eval_batch_f32", "nmpc_eval_batch_f64",
+    "nmpc_last_kernel_ms", "nmpc_kernel_info", "nmpc_selftest", "nmpc_last_error",
+)
+
+_lib: Optional[C.CDLL] = None
+
+
+def library_path() -> str:
+    return _build.LIB_PATH
+
+
+def load_library(build_if_missing: bool = True) -> C.CDLL:
+    """dlopen the in-tree ``libnmpc_hip.so`` (building it with hipcc first if it is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise FileNotFoundError(f"{path} not built; run dyobav-mpcnwta-warehouse_amd/build.py")
+        _build.build()
+    lib = C.CDLL(path)
+    vp, i32 = C.c_void_p, C.c_int32
+    lib.nmpc_last_error.restype = C.c_char_p
+    lib.nmpc_last_error.argtypes = []
+    lib.nmpc_default_config.argtypes = [C.POINTER(NmpcConfigStruct)]
+    lib.nmpc_create.argtypes = [C.POINTER(NmpcConfigStruct), C.POINTER(vp)]
+    lib.nmpc_destroy.argtypes = [vp]
+    lib.nmpc_param_len.argtypes = [vp]
+    lib.nmpc_set_stream.argtypes = [vp, vp]
+    for sfx in ("f32", "f64"):
+        getattr(lib, "nmpc_solve_batch_" + sfx).argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32]
+        getattr(lib, "nmpc_eval_batch_" + sfx).argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp]
+    lib.nmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.nmpc_kernel_info.argtypes = [vp] + [C.POINTER(i32)] * 5
+    lib.nmpc_selftest.argtypes = [vp]
+    for name in EXPORTED_SYMBOLS:
+        if name != "nmpc_last_error":
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc: int) -> int:
+    if rc < 0:
+        raise NmpcError(rc, load_library().nmpc_last_error().decode(errors="replace"))
+    return rc
+
+
+def default_config_struct() -> NmpcConfigStruct:
+    cfg = NmpcConfigStruct()
+    _check(load_library().nmpc_default_config(C.byref(cfg)))
+    return cfg
+
+
+def _suffix(dtype) -> str:
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return "f32"
+    if dtype == np.float64:
+        return "f64"
+    raise TypeError(f"unsupported dtype {dtype}; the kernels compute in float32 or float64")
+
+
+class _Arg:
+    """A host numpy array or a raw device pointer (``int``) to hand to the C ABI."""
+
+    @staticmethod
+    def ptr(x) -> Optional[int]:
+        if x is None:
+            return None
+        if isinstance(x, np.ndarray):
+            assert x.flags.c_contiguous
+            return x.ctypes.data
+        if isinstance(x, int):
+            return x
+        if hasattr(x, "data_ptr"):   # torch tensor (host or device); must be contiguous
+            assert x.is_contiguous()
+            return x.data_ptr()
+        raise TypeError(type(x))
+
+
+class Handle:
+    """RAII wrapper of ``nmpc_handle``: one HIP device + stream + workspace."""
+
+    def __init__(self, cfg: NmpcConfigStruct):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.cfg = cfg
+        _check(self._lib.nmpc_create(C.byref(cfg), C.byref(self._h)))
+        self.np_ = _check(self._lib.nmpc_param_len(self._h))
+        self.n = 2 * cfg.N_hor
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.nmpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------------------------------------
+    def set_stream(self, stream_ptr: Optional[int]):
+        _check(self._lib.nmpc_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def selftest(self) -> int:
+        return _check(self._lib.nmpc_selftest(self._h))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        _check(self._lib.nmpc_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def kernel_info(self) -> dict:
+        v = [C.c_int32() for _ in range(5)]
+        _check(self._lib.nmpc_kernel_info(self._h, *[C.byref(x) for x in v]))
+        keys = ("lds_bytes_f32", "lds_bytes_f64", "lanes_per_step", "waves_per_cu_f32", "waves_per_cu_f64")
+        return dict(zip(keys, (int(x.value) for x in v)))
+
+    def solve_raw(self, dtype, P, B, U, cost=None, status=None, iters=None, u0=None, y=None, y_is_input=False,
+                  c0=None, info=None, sync=True):
+        """Thin call of ``nmpc_solve_batch_*``; every array argument may be numpy, torch or a raw pointer."""
+        fn = getattr(self._lib, "nmpc_solve_batch_" + _suffix(dtype))
+        p = _Arg.ptr
+        _check(fn(self._h, p(P), int(B), p(U), p(cost), p(status), p(iters), p(u0), p(y), int(bool(y_is_input)),
+                  p(c0), p(info), int(bool(sync))))
+
+    def solve(self, P: np.ndarray, u0=None, y0=None, c0=None, dtype=None, want_info=True) -> dict:
+        """Solve a batch held in host memory; returns numpy arrays."""
+        dtype = np.dtype(dtype or P.dtype)
+        P = np.ascontiguousarray(P, dtype=dtype)
+        if P.ndim != 2 or P.shape[1] != self.np_:
+            raise ValueError(f"P must be [B, {self.np_}], got {P.shape}")
+        B = P.shape[0]
+        U = np.empty((B, self.n), dtype=dtype)
+        cost = np.empty(B, dtype=dtype)
+        status = np.empty(B, dtype=np.int32)
+        iters = np.empty((B, 2), dtype=np.int32)
+        y = np.zeros((B, self.n), dtype=dtype) if y0 is None else np.ascontiguousarray(y0, dtype=dtype).copy()
+        u0 = None if u0 is None else np.ascontiguousarray(u0, dtype=dtype)
+        c0 = None if c0 is None else np.ascontiguousarray(c0, dtype=dtype)
+        info = np.empty((B, 8), dtype=dtype) if want_info else None
+        self.solve_raw(dtype, P, B, U, cost, status, iters, u0, y, y0 is not None, c0, info, True)
+        return dict(U=U, cost=cost, status=status, iters=iters, y=y, info=info)
+
+    def eval(self, P: np.ndarray, U: np.ndarray, Y: np.ndarray, Cpen: np.ndarray, grad=True, dtype=None) -> dict:
+        dtype = np.dtype(dtype or P.dtype)
+        P = np.ascontiguousarray(P, dtype=dtype)
+        U = np.ascontiguousarray(U, dtype=dtype)
+        Y = np.ascontiguousarray(Y, dtype=dtype)
+        Cpen = np.ascontiguousarray(Cpen, dtype=dtype)
+        B = P.shape[0]
+        assert P.shape == (B, self.np_) and U.shape == (B, self.n) and Y.shape == (B, self.n) and Cpen.shape == (B,)
+        psi = np.empty(B, dtype=dtype)
+        g = np.empty((B, self.n), dtype=dtype) if grad else None
+        f2 = np.empty(B, dtype=dtype)
+        fn = getattr(self._lib, "nmpc_eval_batch_" + _suffix(dtype))
+        p = _Arg.ptr
+        _check(fn(self._h, p(P), p(U), p(Y), p(Cpen), B, p(psi), p(g), p(f2)))
+        return dict(psi=psi, grad=g, f2sq=f2)

@@ -1,0 +1,598 @@
+// nmpc_capi.hip -- C ABI (include/nmpc_hip.h) over the gfx950 kernels in nmpc_device.h.
+// Host side of the drop-in boundary for `solver.run(p)` of the reference
+// (/root/reference/src/pkg_mpc_tracker/trajectory_tracker.py:54-66, :362). No CPU fallback: every entry point
+// either launches the HIP kernels or returns an error code.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/nmpc_hip.h"
+#include "nmpc_device.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? NMPC_ERR_OUT_OF_MEMORY : NMPC_ERR_HIP, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                                              \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return fail(NMPC_ERR_OUT_OF_MEMORY, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        cap = bytes;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+bool is_device_ptr(const void* ptr)
+{
+    if (!ptr) return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, ptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError(); // plain host memory: clear the sticky error
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+struct Layout {
+    int np, off_rs, off_rv, off_c0, off_c, off_os, off_od, off_qstc, off_qdyn;
+    int lds_alpha, lds_poly, lds_seg, lds_seginv, lds_fl0, lds_fl, lds_total;
+};
+
+int round4(int x) { return (x + 3) & ~3; }
+
+Layout make_layout(const nmpc_config& c)
+{
+    Layout L;
+    const int N = c.N_hor;
+    L.off_rs = 18;
+    L.off_rv = L.off_rs + 3 * N;
+    L.off_c0 = L.off_rv + N;
+    L.off_c = L.off_c0 + 3 * c.Nother;
+    L.off_os = L.off_c + 3 * N * c.Nother;
+    L.off_od = L.off_os + 12 * c.Nstcobs;
+    L.off_qstc = L.off_od + 6 * (N + 1) * c.Ndynobs;
+    L.off_qdyn = L.off_qstc + N;
+    L.np = L.off_qdyn + N;
+    const int ne = c.Ndynobs * (N + 1);
+    L.lds_alpha = nmpc::kEllStride * ne;
+    L.lds_poly = L.lds_alpha + round4(ne);
+    L.lds_seg = L.lds_poly + 12 * c.Nstcobs;
+    L.lds_seginv = L.lds_seg + 4 * N;
+    L.lds_fl0 = L.lds_seginv + round4(N);
+    L.lds_fl = L.lds_fl0 + round4(2 * c.Nother);
+    L.lds_total = L.lds_fl + round4(2 * c.Nother * N);
+    return L;
+}
+
+} // namespace
+
+struct nmpc_handle_s {
+    nmpc_config cfg;
+    Layout lay;
+    int lps;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    DevBuf dP, dU, dcost, dstatus, diters, du0, dy, dc0, dinfo, dY2, dC2, dpsi, dgrad, df2;
+};
+
+namespace {
+
+// second launch-bound argument = minimum waves per SIMD: caps the register allocation at 256 (f32) / 512 (f64)
+template <typename T, int LPS>
+__global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void solve_kernel(nmpc::KParams<T> kp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    nmpc::solve_instance<T, LPS>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
+}
+
+template <typename T, int LPS>
+__global__ __launch_bounds__(64) void eval_kernel(nmpc::KParams<T> kp, nmpc::EvalParams<T> ep)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int inst = blockIdx.x, N = kp.N;
+    nmpc::Instance<T, LPS> I(kp, kp.P + (size_t)inst * kp.np, reinterpret_cast<T*>(smem));
+    I.load();
+    const int kk = I.act ? I.k : 0;
+    T v = ep.U[(size_t)inst * 2 * N + 2 * kk], w = ep.U[(size_t)inst * 2 * N + 2 * kk + 1];
+    T yv = ep.Y[(size_t)inst * 2 * N + kk], yw = ep.Y[(size_t)inst * 2 * N + N + kk];
+    if (!I.act) v = w = yv = yw = 0;
+    const T c = ep.C[inst];
+    T psi, f2, gv, gw;
+    if (ep.grad)
+        I.template eval<true>(v, w, c, yv, yw, psi, f2, gv, gw);
+    else
+        I.template eval<false>(v, w, c, yv, yw, psi, f2, gv, gw);
+    if (I.lead && ep.grad) {
+        ep.grad[(size_t)inst * 2 * N + 2 * I.k] = gv;
+        ep.grad[(size_t)inst * 2 * N + 2 * I.k + 1] = gw;
+    }
+    if (I.lane == 0) {
+        ep.psi[inst] = psi;
+        if (ep.f2sq) ep.f2sq[inst] = f2;
+    }
+}
+
+// wave-primitive self test: integer-valued data so that every summation order gives the same float
+template <typename T>
+__global__ __launch_bounds__(64) void selftest_kernel(int* fails)
+{
+    const int lane = threadIdx.x & 63;
+    int bad = 0;
+    for (int round = 0; round < 8; ++round) {
+        const T x = T(((lane * 37 + round * 11) % 23) - 9);
+        if (nmpc::wave_sum(x) != nmpc::ref_wave_sum(x)) bad |= 1;
+        if (nmpc::wave_scan_incl(x) != nmpc::ref_wave_scan_incl(x)) bad |= 2;
+        if (nmpc::wave_scan_suffix_incl(x) != nmpc::ref_wave_scan_suffix_incl(x)) bad |= 4;
+        const T up3 = nmpc::wave_shift_up<3>(x), up3r = __shfl_up(x, 3, 64);
+        if (up3 != (lane >= 3 ? up3r : T(0))) bad |= 8;
+        const T dn2 = nmpc::wave_shift_down<2>(x), dn2r = __shfl_down(x, 2, 64);
+        if (dn2 != (lane < 62 ? dn2r : T(0))) bad |= 16;
+        if (nmpc::wave_reverse(x) != __shfl(x, 63 - lane, 64)) bad |= 32;
+        if (nmpc::read_lane(x, 17) != __shfl(x, 17, 64)) bad |= 64;
+    }
+    if (bad) atomicOr(fails, bad);
+}
+
+template <typename T>
+void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k)
+{
+    const nmpc_config& c = h->cfg;
+    const Layout& L = h->lay;
+    std::memset(&k, 0, sizeof k);
+    k.N = c.N_hor;
+    k.Nother = c.Nother;
+    k.Nstc = c.Nstcobs;
+    k.Ndyn = c.Ndynobs;
+    k.np = L.np;
+    k.off_rs = L.off_rs;
+    k.off_rv = L.off_rv;
+    k.off_c0 = L.off_c0;
+    k.off_c = L.off_c;
+    k.off_os = L.off_os;
+    k.off_od = L.off_od;
+    k.off_qstc = L.off_qstc;
+    k.off_qdyn = L.off_qdyn;
+    k.lds_alpha = L.lds_alpha;
+    k.lds_poly = L.lds_poly;
+    k.lds_seg = L.lds_seg;
+    k.lds_seginv = L.lds_seginv;
+    k.lds_fl0 = L.lds_fl0;
+    k.lds_fl = L.lds_fl;
+    k.lds_total = L.lds_total;
+    k.ts = (T)c.ts;
+    k.vmin = (T)c.lin_vel_min;
+    k.vmax = (T)c.lin_vel_max;
+    k.wmax = (T)c.ang_vel_max;
+    k.amin = (T)c.lin_acc_min;
+    k.amax = (T)c.lin_acc_max;
+    k.wamax = (T)c.ang_acc_max;
+    k.safe2 = (T)(c.vehicle_width * c.vehicle_width);
+    k.vm = (T)c.vehicle_margin;
+    k.sm = (T)c.social_margin;
+    k.tol = (T)c.tolerance;
+    k.init_tol = (T)c.initial_tolerance;
+    k.delta_tol = (T)c.delta_tolerance;
+    k.c_init = (T)c.initial_penalty;
+    k.pen_update = (T)c.penalty_update_factor;
+    k.tol_update = (T)c.inner_tolerance_update_factor;
+    k.suff_dec = (T)c.sufficient_decrease_coeff;
+    const bool f32 = sizeof(T) == 4;
+    k.lip_eps = (T)(f32 ? c.lip_eps_f32 : c.lip_eps_f64);
+    k.lip_delta = (T)(f32 ? c.lip_delta_f32 : c.lip_delta_f64);
+    k.cbfgs_alpha = (T)c.cbfgs_alpha;
+    k.cbfgs_eps = (T)c.cbfgs_epsilon;
+    k.sy_eps = (T)c.sy_epsilon;
+    k.max_outer = c.max_outer_iterations;
+    k.max_inner = c.max_inner_iterations;
+    k.mem = c.lbfgs_memory;
+}
+
+template <typename T>
+using SolveFn = void (*)(nmpc::KParams<T>);
+template <typename T>
+using EvalFn = void (*)(nmpc::KParams<T>, nmpc::EvalParams<T>);
+
+template <typename T>
+SolveFn<T> pick_solve(int lps)
+{
+    return lps == 3 ? solve_kernel<T, 3> : lps == 2 ? solve_kernel<T, 2> : solve_kernel<T, 1>;
+}
+template <typename T>
+EvalFn<T> pick_eval(int lps)
+{
+    return lps == 3 ? eval_kernel<T, 3> : lps == 2 ? eval_kernel<T, 2> : eval_kernel<T, 1>;
+}
+
+// stage `count` elements: returns the device pointer to use (src itself if already on the device)
+template <typename T>
+int stage_in(nmpc_handle_s* h, DevBuf& buf, const T* src, size_t count, const T** out)
+{
+    if (!src) {
+        *out = nullptr;
+        return 0;
+    }
+    if (is_device_ptr(src)) {
+        *out = src;
+        return 0;
+    }
+    if (int rc = buf.reserve(count * sizeof(T))) return rc;
+    HIP_TRY(hipMemcpyAsync(buf.p, src, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    *out = static_cast<const T*>(buf.p);
+    return 0;
+}
+template <typename T>
+int stage_out(DevBuf& buf, T* dst, size_t count, T** dev, bool* is_host)
+{
+    *is_host = false;
+    if (!dst) {
+        *dev = nullptr;
+        return 0;
+    }
+    if (is_device_ptr(dst)) {
+        *dev = dst;
+        return 0;
+    }
+    if (int rc = buf.reserve(count * sizeof(T))) return rc;
+    *dev = static_cast<T*>(buf.p);
+    *is_host = true;
+    return 0;
+}
+
+template <typename T>
+int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t* status, int32_t* iters,
+                const T* u0, T* y, int32_t y_is_input, const T* c0, T* info, int32_t sync)
+{
+    if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (!P || !U) return fail(NMPC_ERR_INVALID_ARGUMENT, "P and U must not be NULL");
+    if (B < 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "B = %d < 0", B);
+    if (B == 0) return 0;
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const size_t n = 2 * (size_t)h->cfg.N_hor, np = h->lay.np;
+    nmpc::KParams<T> k;
+    fill_kparams(h, k);
+    k.B = B;
+    k.y_is_input = y_is_input;
+    bool hU, hcost, hstatus, hiters, hy, hinfo;
+    int rc;
+    if ((rc = stage_in(h, h->dP, P, (size_t)B * np, &k.P))) return rc;
+    if ((rc = stage_in(h, h->du0, u0, (size_t)B * n, &k.u0))) return rc;
+    if ((rc = stage_in(h, h->dc0, c0, (size_t)B, &k.c0v))) return rc;
+    if ((rc = stage_out(h->dU, U, (size_t)B * n, &k.U, &hU))) return rc;
+    if ((rc = stage_out(h->dcost, cost, (size_t)B, &k.cost, &hcost))) return rc;
+    if ((rc = stage_out(h->dstatus, status, (size_t)B, &k.status, &hstatus))) return rc;
+    if ((rc = stage_out(h->diters, iters, (size_t)B * 2, &k.iters, &hiters))) return rc;
+    if ((rc = stage_out(h->dy, y, (size_t)B * n, &k.y, &hy))) return rc;
+    if ((rc = stage_out(h->dinfo, info, (size_t)B * 8, &k.info, &hinfo))) return rc;
+    if (hy && y_is_input) HIP_TRY(hipMemcpyAsync(k.y, y, (size_t)B * n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+
+    const size_t lds_bytes = (size_t)h->lay.lds_total * sizeof(T);
+    SolveFn<T> fn = pick_solve<T>(h->lps);
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(fn, dim3(B), dim3(64), lds_bytes, h->stream, k);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+
+    const bool any_host = hU || hcost || hstatus || hiters || hy || hinfo;
+    if (hU) HIP_TRY(hipMemcpyAsync(U, k.U, (size_t)B * n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    if (hcost) HIP_TRY(hipMemcpyAsync(cost, k.cost, (size_t)B * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    if (hstatus)
+        HIP_TRY(hipMemcpyAsync(status, k.status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (hiters)
+        HIP_TRY(hipMemcpyAsync(iters, k.iters, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (hy) HIP_TRY(hipMemcpyAsync(y, k.y, (size_t)B * n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    if (hinfo) HIP_TRY(hipMemcpyAsync(info, k.info, (size_t)B * 8 * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    if (any_host || sync) HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+template <typename T>
+int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C, int32_t B, T* psi, T* grad,
+               T* f2sq)
+{
+    if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (!P || !U || !Y || !C || !psi) return fail(NMPC_ERR_INVALID_ARGUMENT, "P, U, Y, C, psi must not be NULL");
+    if (B <= 0) return B == 0 ? 0 : fail(NMPC_ERR_INVALID_ARGUMENT, "B = %d < 0", B);
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const size_t n = 2 * (size_t)h->cfg.N_hor, np = h->lay.np;
+    nmpc::KParams<T> k;
+    fill_kparams(h, k);
+    k.B = B;
+    nmpc::EvalParams<T> ep;
+    bool hpsi, hgrad, hf2;
+    int rc;
+    if ((rc = stage_in(h, h->dP, P, (size_t)B * np, &k.P))) return rc;
+    if ((rc = stage_in(h, h->du0, U, (size_t)B * n, &ep.U))) return rc;
+    if ((rc = stage_in(h, h->dY2, Y, (size_t)B * n, &ep.Y))) return rc;
+    if ((rc = stage_in(h, h->dC2, C, (size_t)B, &ep.C))) return rc;
+    if ((rc = stage_out(h->dpsi, psi, (size_t)B, &ep.psi, &hpsi))) return rc;
+    if ((rc = stage_out(h->dgrad, grad, (size_t)B * n, &ep.grad, &hgrad))) return rc;
+    if ((rc = stage_out(h->df2, f2sq, (size_t)B, &ep.f2sq, &hf2))) return rc;
+    const size_t lds_bytes = (size_t)h->lay.lds_total * sizeof(T);
+    EvalFn<T> fn = pick_eval<T>(h->lps);
+    hipLaunchKernelGGL(fn, dim3(B), dim3(64), lds_bytes, h->stream, k, ep);
+    HIP_TRY(hipGetLastError());
+    if (hpsi) HIP_TRY(hipMemcpyAsync(psi, ep.psi, (size_t)B * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    if (hgrad) HIP_TRY(hipMemcpyAsync(grad, ep.grad, (size_t)B * n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    if (hf2) HIP_TRY(hipMemcpyAsync(f2sq, ep.f2sq, (size_t)B * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+template <typename T>
+int set_lds_limit(nmpc_handle_s* h)
+{
+    const size_t lds_bytes = (size_t)h->lay.lds_total * sizeof(T);
+    if (lds_bytes > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve<T>(h->lps)),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_eval<T>(h->lps)),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* nmpc_last_error(void) { return g_err.c_str(); }
+
+int nmpc_default_config(nmpc_config* c)
+{
+    if (!c) return fail(NMPC_ERR_INVALID_ARGUMENT, "null config");
+    std::memset(c, 0, sizeof *c);
+    c->abi_version = NMPC_ABI_VERSION;
+    c->device_id = 0;
+    // config/mpc_fast.yaml == config/mpc_default.yaml for everything the solver consumes
+    c->N_hor = 20;
+    c->Nother = 10;
+    c->Nstcobs = 10;
+    c->Ndynobs = 15;
+    c->ts = 0.2;
+    c->lin_vel_min = -0.5;
+    c->lin_vel_max = 1.5;
+    c->ang_vel_max = 0.5;
+    c->lin_acc_min = -1.0;
+    c->lin_acc_max = 1.0;
+    c->ang_acc_max = 3.0;
+    c->vehicle_width = 0.5;
+    c->vehicle_margin = 0.2;
+    c->social_margin = 0.2;
+    c->tolerance = 1e-4;
+    c->initial_tolerance = 1e-4;
+    c->delta_tolerance = 1e-4;
+    c->max_outer_iterations = 10;
+    c->max_inner_iterations = 500;
+    c->lbfgs_memory = 10;
+    c->initial_penalty = 10.0;
+    c->penalty_update_factor = 5.0;
+    c->inner_tolerance_update_factor = 0.1;
+    c->sufficient_decrease_coeff = 0.1;
+    c->lip_eps_f64 = 1e-6;
+    c->lip_delta_f64 = 1e-12;
+    c->lip_eps_f32 = 1e-4;
+    c->lip_delta_f32 = 1e-4;
+    c->cbfgs_alpha = 1.0;
+    c->cbfgs_epsilon = 1e-8;
+    c->sy_epsilon = 1e-10;
+    return 0;
+}
+
+int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
+{
+    if (!cfg || !out) return fail(NMPC_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != NMPC_ABI_VERSION)
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "abi_version %d != %d", cfg->abi_version, NMPC_ABI_VERSION);
+    if (cfg->N_hor < 1 || cfg->N_hor > NMPC_MAX_HORIZON)
+        return fail(NMPC_ERR_UNSUPPORTED, "N_hor = %d outside [1, %d] (one horizon step per lane group)", cfg->N_hor,
+                    NMPC_MAX_HORIZON);
+    if (cfg->Nother < 1 || cfg->Nstcobs < 0 || cfg->Ndynobs < 0)
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "bad dimensions Nother=%d Nstcobs=%d Ndynobs=%d", cfg->Nother,
+                    cfg->Nstcobs, cfg->Ndynobs);
+    if (cfg->lbfgs_memory < 1 || cfg->lbfgs_memory > NMPC_LBFGS_MAX_MEMORY)
+        return fail(NMPC_ERR_UNSUPPORTED, "lbfgs_memory = %d outside [1, %d]", cfg->lbfgs_memory,
+                    NMPC_LBFGS_MAX_MEMORY);
+    if (!(cfg->ts > 0) || cfg->max_outer_iterations < 1 || cfg->max_inner_iterations < 1 ||
+        !(cfg->initial_penalty > 0))
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "bad ts / iteration caps / initial penalty");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(NMPC_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    }
+    if (cfg->device_id < 0 || cfg->device_id >= ndev)
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "device_id %d not in [0, %d)", cfg->device_id, ndev);
+    nmpc_handle_s* h = new (std::nothrow) nmpc_handle_s();
+    if (!h) return fail(NMPC_ERR_OUT_OF_MEMORY, "host allocation failed");
+    h->cfg = *cfg;
+    h->lay = make_layout(*cfg);
+    h->lps = 64 / cfg->N_hor;
+    if (h->lps > 3) h->lps = 3;
+    if (h->lps < 1) h->lps = 1;
+    const size_t lds64 = (size_t)h->lay.lds_total * sizeof(double);
+    const size_t lds32 = (size_t)h->lay.lds_total * sizeof(float);
+    if (lds32 > 160 * 1024) {
+        delete h;
+        return fail(NMPC_ERR_UNSUPPORTED,
+                    "obstacle tables need %zu B of LDS per instance (> 160 KiB): this configuration needs the "
+                    "HBM-streaming kernel, which is not built yet",
+                    lds32);
+    }
+    (void)lds64;
+    hipError_t e = hipSetDevice(cfg->device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e != hipSuccess) {
+        nmpc_destroy(h);
+        return fail(NMPC_ERR_HIP, "handle setup: %s", hipGetErrorString(e));
+    }
+    h->stream = h->own_stream;
+    int rc = set_lds_limit<float>(h);
+    if (rc == 0 && lds64 <= 160 * 1024) rc = set_lds_limit<double>(h);
+    if (rc) {
+        nmpc_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+int nmpc_destroy(nmpc_handle h)
+{
+    if (!h) return 0;
+    (void)hipSetDevice(h->cfg.device_id);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    for (DevBuf* b : {&h->dP, &h->dU, &h->dcost, &h->dstatus, &h->diters, &h->du0, &h->dy, &h->dc0, &h->dinfo,
+                      &h->dY2, &h->dC2, &h->dpsi, &h->dgrad, &h->df2})
+        b->release();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return 0;
+}
+
+int nmpc_param_len(nmpc_handle h)
+{
+    if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
+    return h->lay.np;
+}
+
+int nmpc_set_stream(nmpc_handle h, void* s)
+{
+    if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
+    h->stream = s ? static_cast<hipStream_t>(s) : h->own_stream;
+    return 0;
+}
+
+int nmpc_solve_batch_f32(nmpc_handle h, const float* P, int32_t B, float* U, float* cost, int32_t* status,
+                         int32_t* iters, const float* u0, float* y, int32_t y_is_input, const float* c0, float* info,
+                         int32_t sync)
+{
+    return solve_batch<float>(h, P, B, U, cost, status, iters, u0, y, y_is_input, c0, info, sync);
+}
+
+int nmpc_solve_batch_f64(nmpc_handle h, const double* P, int32_t B, double* U, double* cost, int32_t* status,
+                         int32_t* iters, const double* u0, double* y, int32_t y_is_input, const double* c0,
+                         double* info, int32_t sync)
+{
+    if (h && (size_t)h->lay.lds_total * sizeof(double) > 160 * 1024)
+        return fail(NMPC_ERR_UNSUPPORTED, "f64 tables exceed 160 KiB of LDS for this configuration");
+    return solve_batch<double>(h, P, B, U, cost, status, iters, u0, y, y_is_input, c0, info, sync);
+}
+
+int nmpc_eval_batch_f32(nmpc_handle h, const float* P, const float* U, const float* Y, const float* C, int32_t B,
+                        float* psi, float* grad, float* f2sq)
+{
+    return eval_batch<float>(h, P, U, Y, C, B, psi, grad, f2sq);
+}
+
+int nmpc_eval_batch_f64(nmpc_handle h, const double* P, const double* U, const double* Y, const double* C, int32_t B,
+                        double* psi, double* grad, double* f2sq)
+{
+    if (h && (size_t)h->lay.lds_total * sizeof(double) > 160 * 1024)
+        return fail(NMPC_ERR_UNSUPPORTED, "f64 tables exceed 160 KiB of LDS for this configuration");
+    return eval_batch<double>(h, P, U, Y, C, B, psi, grad, f2sq);
+}
+
+int nmpc_last_kernel_ms(nmpc_handle h, float* ms)
+{
+    if (!h || !ms) return fail(NMPC_ERR_INVALID_ARGUMENT, "null argument");
+    if (!h->timed) return fail(NMPC_ERR_INVALID_ARGUMENT, "no solve has been launched on this handle yet");
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return 0;
+}
+
+int nmpc_kernel_info(nmpc_handle h, int32_t* lds_bytes_f32, int32_t* lds_bytes_f64, int32_t* lanes_per_step,
+                     int32_t* waves_per_cu_f32, int32_t* waves_per_cu_f64)
+{
+    if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const size_t l32 = (size_t)h->lay.lds_total * 4, l64 = (size_t)h->lay.lds_total * 8;
+    if (lds_bytes_f32) *lds_bytes_f32 = (int32_t)l32;
+    if (lds_bytes_f64) *lds_bytes_f64 = (int32_t)l64;
+    if (lanes_per_step) *lanes_per_step = h->lps;
+    if (waves_per_cu_f32) {
+        int nb = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &nb, reinterpret_cast<const void*>(pick_solve<float>(h->lps)), 64, l32));
+        *waves_per_cu_f32 = nb;
+    }
+    if (waves_per_cu_f64) {
+        int nb = 0;
+        if (l64 <= 160 * 1024)
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                &nb, reinterpret_cast<const void*>(pick_solve<double>(h->lps)), 64, l64));
+        *waves_per_cu_f64 = nb;
+    }
+    return 0;
+}
+
+int nmpc_selftest(nmpc_handle h)
+{
+    if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    int* d = nullptr;
+    HIP_TRY(hipMalloc(&d, 2 * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(d, 0, 2 * sizeof(int), h->stream));
+    hipLaunchKernelGGL(selftest_kernel<float>, dim3(1), dim3(64), 0, h->stream, d);
+    hipLaunchKernelGGL(selftest_kernel<double>, dim3(1), dim3(64), 0, h->stream, d + 1);
+    int res[2] = {-1, -1};
+    hipError_t e = hipMemcpyAsync(res, d, sizeof res, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(NMPC_ERR_HIP, "selftest: %s", hipGetErrorString(e));
+    if (res[0] || res[1]) {
+        g_err = "wave primitive self-test failed: f32 mask " + std::to_string(res[0]) + ", f64 mask " +
+                std::to_string(res[1]);
+        return __builtin_popcount(res[0]) + __builtin_popcount(res[1]);
+    }
+    return 0;
+}
+
+} // extern "C"

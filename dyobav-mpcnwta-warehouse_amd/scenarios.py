@@ -92,7 +92,8 @@ def box_halfspaces(cx, cy, hx, hy):
 
 
 def make_batch(B: int, layout: ParamLayout = ParamLayout(), seed: int = 0, n_ped: int = 2, n_hyp: int = 5,
-               ts: float = 0.2, base_speed: float = 1.2, n_boxes: int = 4, dtype=np.float64) -> np.ndarray:
+               ts: float = 0.2, base_speed: float = 1.2, n_boxes: int = 4, ped_mode: str = "toward_robot",
+               dtype=np.float64) -> np.ndarray:
     """SURVEY.md 8d synthetic generator. Returns ``P[B, np]``.
 
     Robot: s0 xy ~ U(-10,10)^2, theta ~ U(-pi,pi); previous action u_m1 = (U(0,1.2), U(-0.3,0.3)).
@@ -101,6 +102,9 @@ def make_batch(B: int, layout: ParamLayout = ParamLayout(), seed: int = 0, n_ped
     Pedestrians: start 3-8 m ahead, +-2 m lateral, walk toward the robot at 1.0-1.5 m/s; hypothesis h fans
     out by (h - (n_hyp-1)/2) * 0.15 rad; ellipse radii 0.2 + 0.05 t, angle 0, alpha 1
     (``main_base.py:293-302``); remaining Ndyn slots zero (``interfaces/mpc_interface.py:82-88``).
+    ``ped_mode="oncoming"`` (not a BASELINE configuration; used by the parity tests) makes the pedestrians walk
+    against the robot's heading +-0.3 rad instead of straight at it, which keeps the hard ellipse constraint
+    feasible for most instances so that the solver converges instead of running into its iteration caps.
     Static: ``n_boxes`` axis-aligned 1 x 2 m boxes within 6 m of the robot; remaining slots zero.
     Other robots: zero (reference default, ``trajectory_tracker.py:295-296``).
     """
@@ -150,8 +154,13 @@ def make_batch(B: int, layout: ParamLayout = ParamLayout(), seed: int = 0, n_ped
         side = rng.uniform(-2.0, 2.0, size=(B, n_ped))
         start = xy[:, None, :] + ahead[..., None] * fwd[:, None, :] + side[..., None] * lat[:, None, :]
         speed = rng.uniform(1.0, 1.5, size=(B, n_ped))
-        to_robot = xy[:, None, :] - start
-        base_ang = np.arctan2(to_robot[..., 1], to_robot[..., 0])
+        if ped_mode == "toward_robot":
+            to_robot = xy[:, None, :] - start
+            base_ang = np.arctan2(to_robot[..., 1], to_robot[..., 0])
+        elif ped_mode == "oncoming":
+            base_ang = (th[:, None] + np.pi) + rng.uniform(-0.3, 0.3, size=(B, n_ped))
+        else:
+            raise ValueError(f"unknown ped_mode {ped_mode!r}")
         t = np.arange(N + 1)[None, None, None, :]
         fan = (np.arange(n_hyp) - (n_hyp - 1) / 2.0) * 0.15
         a = base_ang[:, :, None] + fan[None, None, :]           # [B, ped, hyp]

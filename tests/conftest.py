@@ -1,0 +1,57 @@
+"""pytest configuration: the ``gpu`` marker and shared fixtures.
+
+``-m "not gpu"``: oracle vs golden vectors, host logic, C-ABI export checks (runs without a GPU).
+``-m gpu``      : parity tests proper -- every one calls the HIP kernels through the C ABI of libnmpc_hip.so
+                  and fails loudly (no skip, no fallback) if the library or the device is missing.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+def load_problem_fixture(name):
+    import oracle
+    fx = np.load(os.path.join(GOLDEN, name))
+    N, No, Ns, Nd = (int(v) for v in fx["dims"])
+    pr = oracle.Problem(N, No, Ns, Nd, *(float(v) for v in fx["robot"]))
+    return fx, pr
+
+
+@pytest.fixture(scope="session")
+def problem_n20():
+    return load_problem_fixture("problem_n20.npz")
+
+
+@pytest.fixture(scope="session")
+def problem_small():
+    return load_problem_fixture("problem_small.npz")
+
+
+def config_for(pr, **overrides):
+    """nmpc_config for an oracle.Problem (dims + robot constants) with option overrides."""
+    import dyobav_mpcnwta_warehouse_amd as nm
+    cfg = nm.default_config_struct()
+    cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs = pr.N, pr.Nother, pr.Nstc, pr.Ndyn
+    for k in ("ts", "lin_vel_min", "lin_vel_max", "ang_vel_max", "lin_acc_min", "lin_acc_max", "ang_acc_max",
+              "vehicle_width", "vehicle_margin", "social_margin"):
+        setattr(cfg, k, getattr(pr, k))
+    for k, v in overrides.items():
+        assert hasattr(cfg, k), k
+        setattr(cfg, k, v)
+    return cfg
