@@ -186,15 +186,33 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: CPU affinity capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:  # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(layout, P_host, U_gpu, status_gpu):
     """The CPU oracle (kind "port": C restatement of the OpEn algorithm, fp64) on this box's host cores, on the
     timed batch itself (bounded: <= 2048 instances), all cores via OpenMP over instances. Reported, not tuned."""
     import oracle
     pr = oracle.Problem(layout.N, layout.Nother, layout.Nstc, layout.Ndyn)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = usable_cores()
     sample = min(P_host.shape[0], 2048)
     Ps = P_host[:sample]
     oracle.solve_batch(pr, oracle.Options(), Ps[:min(sample, cores)], nthreads=cores)   # warm the threads

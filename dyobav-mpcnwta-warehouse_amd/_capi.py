@@ -62,6 +62,13 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64. If this library
+    # pulled in /opt/rocm's copies first, a later `import torch` would find "No HIP GPUs". Loading torch first
+    # makes the dynamic linker resolve our NEEDED libamdhip64.so.* to the copy that is already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         if not build_if_missing:
