@@ -74,7 +74,7 @@ bool is_device_ptr(const void* ptr)
 
 struct Layout {
     int np, off_rs, off_rv, off_c0, off_c, off_os, off_od, off_qstc, off_qdyn;
-    int lds_alpha, lds_poly, lds_seg, lds_seginv, lds_fl0, lds_fl, lds_total;
+    int lds_alpha, lds_poly, lds_seg, lds_seginv, lds_fl0, lds_fl, lds_iflag, lds_total;
 };
 
 int round4(int x) { return (x + 3) & ~3; }
@@ -99,7 +99,8 @@ Layout make_layout(const nmpc_config& c)
     L.lds_seginv = L.lds_seg + 4 * N;
     L.lds_fl0 = L.lds_seginv + round4(N);
     L.lds_fl = L.lds_fl0 + round4(2 * c.Nother);
-    L.lds_total = L.lds_fl + round4(2 * c.Nother * N);
+    L.lds_iflag = L.lds_fl + round4(2 * c.Nother * N);
+    L.lds_total = L.lds_iflag + round4(c.Ndynobs); // int flags / compaction map (an int fits in a T)
     return L;
 }
 
@@ -138,11 +139,12 @@ __global__ __launch_bounds__(64) void eval_kernel(nmpc::KParams<T> kp, nmpc::Eva
     T yv = ep.Y[(size_t)inst * 2 * N + kk], yw = ep.Y[(size_t)inst * 2 * N + N + kk];
     if (!I.act) v = w = yv = yw = 0;
     const T c = ep.C[inst];
+    const T icd = T(1) / (c > T(1) ? c : T(1));
     T psi, f2, gv, gw;
     if (ep.grad)
-        I.template eval<true>(v, w, c, yv, yw, psi, f2, gv, gw);
+        I.template eval<true>(v, w, c, icd, yv, yw, psi, f2, gv, gw);
     else
-        I.template eval<false>(v, w, c, yv, yw, psi, f2, gv, gw);
+        I.template eval<false>(v, w, c, icd, yv, yw, psi, f2, gv, gw);
     if (I.lead && ep.grad) {
         ep.grad[(size_t)inst * 2 * N + 2 * I.k] = gv;
         ep.grad[(size_t)inst * 2 * N + 2 * I.k + 1] = gw;
@@ -199,8 +201,10 @@ void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k)
     k.lds_seginv = L.lds_seginv;
     k.lds_fl0 = L.lds_fl0;
     k.lds_fl = L.lds_fl;
+    k.lds_iflag = L.lds_iflag;
     k.lds_total = L.lds_total;
     k.ts = (T)c.ts;
+    k.inv_ts = (T)(1.0 / c.ts);
     k.vmin = (T)c.lin_vel_min;
     k.vmax = (T)c.lin_vel_max;
     k.wmax = (T)c.ang_vel_max;

@@ -53,29 +53,52 @@ __device__ __forceinline__ double read_lane(double x, int lane)
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// ---- f32: x += dpp(x) as ONE VALU instruction (v_add_f32_dpp). hipcc lowers update_dpp + add to
+//      v_mov_b32 (old) + s_nop + v_mov_b32_dpp + v_add (3-4 issue slots per step); the fused form is one.
+//      "s_nop 1" covers the 2 wait states a DPP read needs after a VALU write of the same VGPR.
+#define NMPC_DPP_ADD(x, ctrl) asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " ctrl : "+v"(x))
+
 // Sum over the 64 lanes; the result is wave-uniform (read back from lane 63 into scalar registers).
-template <typename T>
-__device__ __forceinline__ T wave_sum(T x)
+__device__ __forceinline__ float wave_sum(float x)
+{
+    NMPC_DPP_ADD(x, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    NMPC_DPP_ADD(x, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    NMPC_DPP_ADD(x, "row_half_mirror row_mask:0xf bank_mask:0xf");
+    NMPC_DPP_ADD(x, "row_mirror row_mask:0xf bank_mask:0xf");        // every lane of a row holds the row sum
+    NMPC_DPP_ADD(x, "row_bcast:15 row_mask:0xa bank_mask:0xf");      // rows 1,3 += rows 0,2
+    NMPC_DPP_ADD(x, "row_bcast:31 row_mask:0xc bank_mask:0xf");      // rows 2,3 += rows 0+1
+    return read_lane(x, 63);
+}
+__device__ __forceinline__ double wave_sum(double x)
 {
     x += dpp_mov<DPP_QUAD_1032>(x, x);
     x += dpp_mov<DPP_QUAD_2301>(x, x);
     x += dpp_mov<DPP_ROW_HALF_MIRROR>(x, x);
-    x += dpp_mov<DPP_ROW_MIRROR>(x, x);                 // every lane of a row holds the row sum
-    x += dpp_mov<DPP_ROW_BCAST15, 0xa>(T(0), x);        // rows 1,3 += rows 0,2
-    x += dpp_mov<DPP_ROW_BCAST31, 0xc>(T(0), x);        // rows 2,3 += rows 0+1
+    x += dpp_mov<DPP_ROW_MIRROR>(x, x);
+    x += dpp_mov<DPP_ROW_BCAST15, 0xa>(0.0, x);
+    x += dpp_mov<DPP_ROW_BCAST31, 0xc>(0.0, x);
     return read_lane(x, 63);
 }
 
 // Inclusive prefix sum over lanes 0..63 (lane i gets x_0 + ... + x_i).
-template <typename T>
-__device__ __forceinline__ T wave_scan_incl(T x)
+__device__ __forceinline__ float wave_scan_incl(float x)
 {
-    x += dpp_mov<DPP_ROW_SHR0 + 1>(T(0), x);
-    x += dpp_mov<DPP_ROW_SHR0 + 2>(T(0), x);
-    x += dpp_mov<DPP_ROW_SHR0 + 4>(T(0), x);
-    x += dpp_mov<DPP_ROW_SHR0 + 8>(T(0), x);
-    x += dpp_mov<DPP_ROW_BCAST15, 0xa>(T(0), x);
-    x += dpp_mov<DPP_ROW_BCAST31, 0xc>(T(0), x);
+    NMPC_DPP_ADD(x, "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    NMPC_DPP_ADD(x, "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    NMPC_DPP_ADD(x, "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    NMPC_DPP_ADD(x, "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    NMPC_DPP_ADD(x, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    NMPC_DPP_ADD(x, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+    return x;
+}
+__device__ __forceinline__ double wave_scan_incl(double x)
+{
+    x += dpp_mov<DPP_ROW_SHR0 + 1>(0.0, x);
+    x += dpp_mov<DPP_ROW_SHR0 + 2>(0.0, x);
+    x += dpp_mov<DPP_ROW_SHR0 + 4>(0.0, x);
+    x += dpp_mov<DPP_ROW_SHR0 + 8>(0.0, x);
+    x += dpp_mov<DPP_ROW_BCAST15, 0xa>(0.0, x);
+    x += dpp_mov<DPP_ROW_BCAST31, 0xc>(0.0, x);
     return x;
 }
 
