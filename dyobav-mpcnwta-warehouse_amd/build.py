@@ -13,7 +13,8 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "libnmpc_hip.so")
+# NMPC_HIP_LIBRARY: load an alternative build of the same C ABI (A/B tests of kernel variants)
+LIB_PATH = os.environ.get("NMPC_HIP_LIBRARY") or os.path.join(PKG_DIR, "libnmpc_hip.so")
 SOURCES = ("nmpc_capi.hip",)
 HEADERS = ("nmpc_device.h", "wave_ops.h", os.path.join("..", "..", "include", "nmpc_hip.h"))
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",

@@ -74,7 +74,7 @@ bool is_device_ptr(const void* ptr)
 
 struct Layout {
     int np, off_rs, off_rv, off_c0, off_c, off_os, off_od, off_qstc, off_qdyn;
-    int lds_alpha, lds_poly, lds_seg, lds_seginv, lds_fl0, lds_fl, lds_iflag, lds_total;
+    int lds_alpha, lds_poly, lds_seg, lds_seginv, lds_fl0, lds_fl, lds_iflag, lds_hist, lds_rho, lds_total;
 };
 
 int round4(int x) { return (x + 3) & ~3; }
@@ -100,7 +100,9 @@ Layout make_layout(const nmpc_config& c)
     L.lds_fl0 = L.lds_seginv + round4(N);
     L.lds_fl = L.lds_fl0 + round4(2 * c.Nother);
     L.lds_iflag = L.lds_fl + round4(2 * c.Nother * N);
-    L.lds_total = L.lds_iflag + round4(c.Ndynobs); // int flags / compaction map (an int fits in a T)
+    L.lds_hist = L.lds_iflag + round4(c.Ndynobs);  // int flags / compaction map (an int fits in a T)
+    L.lds_rho = L.lds_hist + 4 * nmpc::kMem * N;    // L-BFGS ring: kMem x N x (s_v, s_w, y_v, y_w)
+    L.lds_total = L.lds_rho + round4(2 * nmpc::kMem); // rho[kMem], alpha[kMem]
     return L;
 }
 
@@ -119,9 +121,15 @@ struct nmpc_handle_s {
 
 namespace {
 
-// second launch-bound argument = minimum waves per SIMD: caps the register allocation at 256 (f32) / 512 (f64)
+// second launch-bound argument = minimum waves per SIMD; it caps the register allocation (512 / waves)
+#ifndef NMPC_WPE_F32
+#define NMPC_WPE_F32 2
+#endif
+#ifndef NMPC_WPE_F64
+#define NMPC_WPE_F64 1
+#endif
 template <typename T, int LPS>
-__global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void solve_kernel(nmpc::KParams<T> kp)
+__global__ __launch_bounds__(64, (sizeof(T) == 4 ? NMPC_WPE_F32 : NMPC_WPE_F64)) void solve_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     nmpc::solve_instance<T, LPS>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
@@ -171,6 +179,19 @@ __global__ __launch_bounds__(64) void selftest_kernel(int* fails)
         const T dn2 = nmpc::wave_shift_down<2>(x), dn2r = __shfl_down(x, 2, 64);
         if (dn2 != (lane < 62 ? dn2r : T(0))) bad |= 16;
         if (nmpc::wave_reverse(x) != __shfl(x, 63 - lane, 64)) bad |= 32;
+        {
+            T a = x, b = T(3) - x;
+            nmpc::wave_scan_incl2(a, b);
+            if (a != nmpc::ref_wave_scan_incl(x) || b != nmpc::ref_wave_scan_incl(T(3) - x)) bad |= 128;
+            T c = x, d = T(2) * x;
+            nmpc::wave_scan_suffix_incl2(c, d);
+            if (c != nmpc::ref_wave_scan_suffix_incl(x) || d != nmpc::ref_wave_scan_suffix_incl(T(2) * x)) bad |= 256;
+            T s1, s2, s3;
+            nmpc::wave_sum2(x, T(1) + x, s1, s2);
+            if (s1 != nmpc::ref_wave_sum(x) || s2 != nmpc::ref_wave_sum(T(1) + x)) bad |= 512;
+            nmpc::wave_sum3(x, T(2) - x, T(5) * x, s1, s2, s3);
+            if (s1 != nmpc::ref_wave_sum(x) || s2 != nmpc::ref_wave_sum(T(2) - x) || s3 != nmpc::ref_wave_sum(T(5) * x)) bad |= 1024;
+        }
         if (nmpc::read_lane(x, 17) != __shfl(x, 17, 64)) bad |= 64;
     }
     if (bad) atomicOr(fails, bad);
@@ -202,6 +223,8 @@ void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k)
     k.lds_fl0 = L.lds_fl0;
     k.lds_fl = L.lds_fl;
     k.lds_iflag = L.lds_iflag;
+    k.lds_hist = L.lds_hist;
+    k.lds_rho = L.lds_rho;
     k.lds_total = L.lds_total;
     k.ts = (T)c.ts;
     k.inv_ts = (T)(1.0 / c.ts);
@@ -307,7 +330,8 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
     if ((rc = stage_out(h->dstatus, status, (size_t)B, &k.status, &hstatus))) return rc;
     if ((rc = stage_out(h->diters, iters, (size_t)B * 2, &k.iters, &hiters))) return rc;
     if ((rc = stage_out(h->dy, y, (size_t)B * n, &k.y, &hy))) return rc;
-    if ((rc = stage_out(h->dinfo, info, (size_t)B * 8, &k.info, &hinfo))) return rc;
+    const size_t info_row = 8 + nmpc::kProfSlots; // 8 in the shipped library (kProfSlots = 0)
+    if ((rc = stage_out(h->dinfo, info, (size_t)B * info_row, &k.info, &hinfo))) return rc;
     if (hy && y_is_input) HIP_TRY(hipMemcpyAsync(k.y, y, (size_t)B * n * sizeof(T), hipMemcpyHostToDevice, h->stream));
 
     const size_t lds_bytes = (size_t)h->lay.lds_total * sizeof(T);
@@ -326,7 +350,8 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
     if (hiters)
         HIP_TRY(hipMemcpyAsync(iters, k.iters, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     if (hy) HIP_TRY(hipMemcpyAsync(y, k.y, (size_t)B * n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
-    if (hinfo) HIP_TRY(hipMemcpyAsync(info, k.info, (size_t)B * 8 * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    if (hinfo)
+        HIP_TRY(hipMemcpyAsync(info, k.info, (size_t)B * info_row * sizeof(T), hipMemcpyDeviceToHost, h->stream));
     if (any_host || sync) HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }

@@ -53,20 +53,21 @@ __device__ __forceinline__ double read_lane(double x, int lane)
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-// ---- f32: x += dpp(x) as ONE VALU instruction (v_add_f32_dpp). hipcc lowers update_dpp + add to
-//      v_mov_b32 (old) + s_nop + v_mov_b32_dpp + v_add (3-4 issue slots per step); the fused form is one.
-//      "s_nop 1" covers the 2 wait states a DPP read needs after a VALU write of the same VGPR.
-#define NMPC_DPP_ADD(x, ctrl) asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " ctrl : "+v"(x))
+// ---- f32 reductions / scans: each step is x += dpp(x) as ONE VALU instruction (v_add_f32_dpp); hipcc lowers
+//      update_dpp + add to v_mov (old) + s_nop + v_mov_dpp + v_add, and pads every separate asm statement with
+//      its own s_nop, so a whole chain is written as one asm block. "s_nop 1" = the 2 wait states a DPP read
+//      needs after a VALU write of the same VGPR; in the 2-/3-way versions the other chains fill those slots.
 
 // Sum over the 64 lanes; the result is wave-uniform (read back from lane 63 into scalar registers).
 __device__ __forceinline__ float wave_sum(float x)
 {
-    NMPC_DPP_ADD(x, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
-    NMPC_DPP_ADD(x, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
-    NMPC_DPP_ADD(x, "row_half_mirror row_mask:0xf bank_mask:0xf");
-    NMPC_DPP_ADD(x, "row_mirror row_mask:0xf bank_mask:0xf");        // every lane of a row holds the row sum
-    NMPC_DPP_ADD(x, "row_bcast:15 row_mask:0xa bank_mask:0xf");      // rows 1,3 += rows 0,2
-    NMPC_DPP_ADD(x, "row_bcast:31 row_mask:0xc bank_mask:0xf");      // rows 2,3 += rows 0+1
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"     // row sums everywhere
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"    // rows 1,3 += rows 0,2
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"        // rows 2,3 += rows 0+1
+        : "+v"(x));
     return read_lane(x, 63);
 }
 __device__ __forceinline__ double wave_sum(double x)
@@ -80,16 +81,67 @@ __device__ __forceinline__ double wave_sum(double x)
     return read_lane(x, 63);
 }
 
+// Two / three independent sums at once with interleaved chains.
+#define NMPC_P2(ctrl) "s_nop 0\n\tv_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\t"
+#define NMPC_P3(ctrl) \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl "\n\t"
+__device__ __forceinline__ void wave_sum2(float x, float y, float& sx, float& sy)
+{
+    asm("s_nop 0\n\t" NMPC_P2("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+            NMPC_P2("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                NMPC_P2("row_half_mirror row_mask:0xf bank_mask:0xf") NMPC_P2("row_mirror row_mask:0xf bank_mask:0xf")
+                    NMPC_P2("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                        NMPC_P2("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(x), "+v"(y));
+    sx = read_lane(x, 63);
+    sy = read_lane(y, 63);
+}
+__device__ __forceinline__ void wave_sum3(float x, float y, float z, float& sx, float& sy, float& sz)
+{
+    asm("s_nop 1\n\t" NMPC_P3("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+            NMPC_P3("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                NMPC_P3("row_half_mirror row_mask:0xf bank_mask:0xf") NMPC_P3("row_mirror row_mask:0xf bank_mask:0xf")
+                    NMPC_P3("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                        NMPC_P3("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(x), "+v"(y), "+v"(z));
+    sx = read_lane(x, 63);
+    sy = read_lane(y, 63);
+    sz = read_lane(z, 63);
+}
+__device__ __forceinline__ void wave_sum2(double x, double y, double& sx, double& sy)
+{
+    sx = wave_sum(x);
+    sy = wave_sum(y);
+}
+__device__ __forceinline__ void wave_sum3(double x, double y, double z, double& sx, double& sy, double& sz)
+{
+    sx = wave_sum(x);
+    sy = wave_sum(y);
+    sz = wave_sum(z);
+}
+
 // Inclusive prefix sum over lanes 0..63 (lane i gets x_0 + ... + x_i).
 __device__ __forceinline__ float wave_scan_incl(float x)
 {
-    NMPC_DPP_ADD(x, "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    NMPC_DPP_ADD(x, "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    NMPC_DPP_ADD(x, "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    NMPC_DPP_ADD(x, "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    NMPC_DPP_ADD(x, "row_bcast:15 row_mask:0xa bank_mask:0xf");
-    NMPC_DPP_ADD(x, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(x));
     return x;
+}
+// two prefix sums with interleaved chains
+__device__ __forceinline__ void wave_scan_incl2(float& x, float& y)
+{
+    asm("s_nop 0\n\t" NMPC_P2("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+            NMPC_P2("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                NMPC_P2("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                    NMPC_P2("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                        NMPC_P2("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                            NMPC_P2("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(x), "+v"(y));
 }
 __device__ __forceinline__ double wave_scan_incl(double x)
 {
@@ -101,19 +153,63 @@ __device__ __forceinline__ double wave_scan_incl(double x)
     x += dpp_mov<DPP_ROW_BCAST31, 0xc>(0.0, x);
     return x;
 }
+__device__ __forceinline__ void wave_scan_incl2(double& x, double& y)
+{
+    x = wave_scan_incl(x);
+    y = wave_scan_incl(y);
+}
+
+// Inclusive suffix sum (lane i gets x_i + ... + x_63): in-row suffix with row_shl, then the totals of the rows
+// above (they sit in the first lane of each row) are added from scalar registers. No LDS crossbar involved.
+template <typename T>
+__device__ __forceinline__ T wave_suffix_fix_rows(T x)
+{
+    const T t1 = read_lane(x, 16), t2 = read_lane(x, 32), t3 = read_lane(x, 48);
+    const int row = (int)(threadIdx.x & 63) >> 4;
+    const T s23 = t2 + t3, s123 = t1 + s23;
+    const T add = row == 0 ? s123 : row == 1 ? s23 : row == 2 ? t3 : T(0);
+    return x + add;
+}
+__device__ __forceinline__ float wave_scan_suffix_incl(float x)
+{
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+        : "+v"(x));
+    return wave_suffix_fix_rows(x);
+}
+__device__ __forceinline__ void wave_scan_suffix_incl2(float& x, float& y)
+{
+    asm("s_nop 0\n\t" NMPC_P2("row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+            NMPC_P2("row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                NMPC_P2("row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                    NMPC_P2("row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        : "+v"(x), "+v"(y));
+    x = wave_suffix_fix_rows(x);
+    y = wave_suffix_fix_rows(y);
+}
+__device__ __forceinline__ double wave_scan_suffix_incl(double x)
+{
+    x += dpp_mov<0x100 + 1, 0xf, 0xf, true>(0.0, x); // row_shl:n = 0x100 + n
+    x += dpp_mov<0x100 + 2, 0xf, 0xf, true>(0.0, x);
+    x += dpp_mov<0x100 + 4, 0xf, 0xf, true>(0.0, x);
+    x += dpp_mov<0x100 + 8, 0xf, 0xf, true>(0.0, x);
+    return wave_suffix_fix_rows(x);
+}
+__device__ __forceinline__ void wave_scan_suffix_incl2(double& x, double& y)
+{
+    x = wave_scan_suffix_incl(x);
+    y = wave_scan_suffix_incl(y);
+}
+#undef NMPC_P2
+#undef NMPC_P3
 
 // lane i <- lane 63-i
 template <typename T>
 __device__ __forceinline__ T wave_reverse(T x)
 {
     return __shfl(x, 63 - (int)(threadIdx.x & 63), 64);
-}
-
-// Inclusive suffix sum (lane i gets x_i + ... + x_63).
-template <typename T>
-__device__ __forceinline__ T wave_scan_suffix_incl(T x)
-{
-    return wave_reverse(wave_scan_incl(wave_reverse(x)));
 }
 
 // lane i <- lane i-S (zeros shifted in at the bottom)
