@@ -1,0 +1,58 @@
+"""Multi-GPU: the batch of independent MPC problems is split into contiguous shards, one process per GPU
+(``torch.distributed``; backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests). The solve needs no
+communication; the only collective is the gather of the results: ``(B/G) x (2N)`` controls plus
+``(B/G) x 4`` scalars per rank -- 11.5 MB per GPU at B = 524288, far below one xGMI link-second.
+
+The reference has no counterpart (its evaluation loop ``main_base.py:448-464`` is sequential).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple
+
+import numpy as np
+
+
+def shard_bounds(B: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced partition: ranks < B % G get one extra instance. Returns [lo, hi)."""
+    if not (0 <= rank < world_size):
+        raise ValueError(f"rank {rank} outside [0, {world_size})")
+    base, extra = divmod(B, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_gather_ragged(local, counts, group=None):
+    """All-gather of per-rank tensors whose leading dimension differs by at most one (``shard_bounds``): pad to the
+    largest shard, one ``all_gather_into_tensor``, strip the padding."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    mx = max(counts)
+    pad = local
+    if local.shape[0] < mx:
+        pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
+    out = local.new_empty((world * mx,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(world)], dim=0)
+
+
+def solve_sharded(P_full: Optional[np.ndarray], solve_local: Callable[[np.ndarray], Dict[str, np.ndarray]],
+                  device: str = "cuda", group=None) -> Dict[str, np.ndarray]:
+    """Every rank solves rows ``shard_bounds(B, G, rank)`` of ``P_full`` with ``solve_local`` (e.g.
+    ``Handle.solve``) and receives the gathered ``U``, ``cost``, ``status``, ``iters`` of the whole batch.
+
+    ``P_full`` must be the same array on every rank (deterministic generators make that free); only the local
+    rows are touched, so ranks may also pass an array whose other rows are uninitialised.
+    """
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B = P_full.shape[0]
+    lo, hi = shard_bounds(B, world, rank)
+    counts = [shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world)]
+    res = solve_local(np.ascontiguousarray(P_full[lo:hi]))
+    out = {}
+    for key in ("U", "cost", "status", "iters"):
+        t = torch.from_numpy(np.ascontiguousarray(res[key])).to(device)
+        out[key] = all_gather_ragged(t, counts, group).cpu().numpy()
+    return out

@@ -1,0 +1,167 @@
+"""The solver object the reference imports from its generated module, backed by the HIP kernels.
+
+Reference interface being mirrored (``/root/reference/src/pkg_mpc_tracker/trajectory_tracker.py``):
+
+* ``built_solver = __import__(optimizer_name); self.solver = built_solver.solver()``           (:58-61)
+* ``solution = self.solver.run(parameters)`` with a flat Python list of floats               (:362)
+* attributes read from the result: ``solution``, ``cost``, ``exit_status``, ``solve_time_ms``  (:364-367)
+* stub signature ``run(p, initial_guess, initial_lagrange_multipliers, initial_penalty)``      (:13-15)
+
+plus the batched front end (``BatchSolver``) that the reference does not have: B independent problems per
+launch, inputs/outputs as numpy arrays or device tensors.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import _capi
+from ._capi import EXIT_STATUS_NAMES, Handle, NmpcConfigStruct, default_config_struct
+
+_ROBOT_FIELDS = ("ts", "lin_vel_min", "lin_vel_max", "ang_vel_max", "lin_acc_min", "lin_acc_max", "ang_acc_max",
+                 "vehicle_width", "vehicle_margin", "social_margin")
+
+
+def make_config(mpc_config=None, robot_spec=None, device_id: int = 0, **overrides) -> NmpcConfigStruct:
+    """``nmpc_config`` from the reference-style configuration objects (``configs.MpcConfiguration`` /
+    ``configs.CircularRobotSpecification``); unspecified values are the OpEn defaults the reference builds with
+    (``solver_build/mpc_builder.py:187-195``).
+
+    ``max_solver_time`` (a wall-clock cap in the reference) has no counterpart: a GPU batch cannot stop single
+    instances on a timer, so termination is by OpEn's iteration caps only (``max_outer_iterations`` x
+    ``max_inner_iterations``); pass smaller caps through ``overrides`` to bound latency.
+    """
+    cfg = default_config_struct()
+    cfg.device_id = device_id
+    if mpc_config is not None:
+        cfg.N_hor, cfg.Nother = int(mpc_config.N_hor), int(mpc_config.Nother)
+        cfg.Nstcobs, cfg.Ndynobs = int(mpc_config.Nstcobs), int(mpc_config.Ndynobs)
+        if int(mpc_config.ns) != 3 or int(mpc_config.nu) != 2 or int(mpc_config.nq) != 10 or \
+                int(mpc_config.nstcobs) != 12 or int(mpc_config.ndynobs) != 6:
+            raise ValueError("the kernels implement ns=3, nu=2, nq=10, nstcobs=12, ndynobs=6 (the shipped yaml values)")
+        cfg.ts = float(mpc_config.ts)
+    if robot_spec is not None:
+        for k in _ROBOT_FIELDS:
+            setattr(cfg, k, float(getattr(robot_spec, k)))
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise TypeError(f"unknown solver option {k!r}")
+        setattr(cfg, k, v)
+    return cfg
+
+
+@dataclass
+class OptimizerSolution:
+    """Fields of OpEn's generated ``OptimizerSolution``."""
+    exit_status: str
+    num_outer_iterations: int
+    num_inner_iterations: int
+    last_problem_norm_fpr: float
+    f1_infeasibility: float
+    f2_norm: float
+    solve_time_ms: float
+    penalty: float
+    solution: List[float]
+    lagrange_multipliers: List[float]
+    cost: float
+
+
+class Solver:
+    """One-problem-at-a-time facade: ``solver().run(p)`` == a batch of one through ``nmpc_solve_batch_*``.
+
+    State carried between calls, as in OpEn's Python binding (recalled): when no
+    ``initial_lagrange_multipliers`` are passed, the multipliers left by the previous call are reused
+    (``keep_multipliers=False`` resets them to zero every call instead).
+    """
+
+    def __init__(self, config: Optional[NmpcConfigStruct] = None, dtype=np.float64, keep_multipliers: bool = True):
+        self.config = config if config is not None else default_config_struct()
+        self.dtype = np.dtype(dtype)
+        self.keep_multipliers = keep_multipliers
+        self._handle = Handle(self.config)
+        self.num_parameters = self._handle.np_
+        self.num_decision_variables = self._handle.n
+        self._y = np.zeros((1, self._handle.n), dtype=self.dtype)
+
+    def run(self, p, initial_guess=None, initial_lagrange_multipliers=None, initial_penalty=None):
+        p = np.asarray(p, dtype=self.dtype).reshape(1, -1)
+        n = self.num_decision_variables
+        if p.shape[1] != self.num_parameters:
+            print(f"1600 -> wrong number of parameters: expected {self.num_parameters}, got {p.shape[1]}")
+            return None
+        u0 = None
+        if initial_guess is not None:
+            u0 = np.asarray(initial_guess, dtype=self.dtype).reshape(1, -1)
+            if u0.shape[1] != n:
+                print(f"1700 -> wrong length of initial guess: expected {n}, got {u0.shape[1]}")
+                return None
+        if initial_lagrange_multipliers is not None:
+            y = np.asarray(initial_lagrange_multipliers, dtype=self.dtype).reshape(1, -1).copy()
+            if y.shape[1] != n:
+                print(f"1800 -> wrong dimension of Lagrange multipliers: expected {n}, got {y.shape[1]}")
+                return None
+        elif self.keep_multipliers:
+            y = self._y.copy()
+        else:
+            y = np.zeros((1, n), dtype=self.dtype)
+        c0 = None if initial_penalty is None else np.asarray([initial_penalty], dtype=self.dtype)
+        tic = time.perf_counter()
+        out = self._handle.solve(p, u0=u0, y0=y, c0=c0, dtype=self.dtype)
+        wall_ms = (time.perf_counter() - tic) * 1e3
+        status = int(out["status"][0])
+        if status == 3:  # OpEn: Err(NotFiniteComputation) -> binding returns None
+            print("2000 -> Problem solution failed")
+            return None
+        self._y = out["y"].astype(self.dtype)
+        info = out["info"][0]
+        return OptimizerSolution(
+            exit_status=EXIT_STATUS_NAMES[status], num_outer_iterations=int(out["iters"][0, 0]),
+            num_inner_iterations=int(out["iters"][0, 1]), last_problem_norm_fpr=float(info[0]),
+            f1_infeasibility=float(info[2] / info[3]) if info[3] else float(info[2]), f2_norm=float(info[1]),
+            solve_time_ms=wall_ms, penalty=float(info[3]), solution=[float(v) for v in out["U"][0]],
+            lagrange_multipliers=[float(v) for v in out["y"][0]], cost=float(out["cost"][0]))
+
+    def close(self):
+        self._handle.close()
+
+
+def solver(config: Optional[NmpcConfigStruct] = None, dtype=np.float64, **kwargs) -> Solver:
+    """Factory with the name the generated OpEn module exports (``<optimizer_name>.solver()``)."""
+    return Solver(config, dtype=dtype, **kwargs)
+
+
+@dataclass
+class BatchResult:
+    U: np.ndarray
+    cost: np.ndarray
+    status: np.ndarray
+    iters: np.ndarray
+    y: np.ndarray
+    info: np.ndarray
+    kernel_ms: float = 0.0
+    exit_status: List[str] = field(default_factory=list)
+
+
+class BatchSolver:
+    """B independent MPC problems per launch (robots x Monte-Carlo scenarios)."""
+
+    def __init__(self, config: Optional[NmpcConfigStruct] = None, dtype=np.float32):
+        self.config = config if config is not None else default_config_struct()
+        self.dtype = np.dtype(dtype)
+        self.handle = Handle(self.config)
+        self.num_parameters = self.handle.np_
+        self.num_decision_variables = self.handle.n
+
+    def run_batch(self, P: np.ndarray, u0=None, y0=None, c0=None) -> BatchResult:
+        out = self.handle.solve(np.asarray(P), u0=u0, y0=y0, c0=c0, dtype=self.dtype)
+        return BatchResult(out["U"], out["cost"], out["status"], out["iters"], out["y"], out["info"],
+                           self.handle.last_kernel_ms(), [EXIT_STATUS_NAMES[int(s)] for s in out["status"]])
+
+    def close(self):
+        self.handle.close()
+
+
+__all__ = ["make_config", "OptimizerSolution", "Solver", "solver", "BatchSolver", "BatchResult", "_capi"]
