@@ -41,6 +41,23 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
 
 
+def measured_traffic(workload, dtype, batch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and
+    WRITE_SIZE collected in separate passes, gfx950 correction applied; profiles/rNN_<workload>_traffic.json).
+    A counter pass cannot run inside the timed process, so the latest committed measurement that matches the
+    workload is reported; None if there is none."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("workload") == workload and rec.get("dtype") == dtype and rec.get("batch") == batch:
+            best = rec
+    return None if best is None else float(best["hbm_bytes_per_launch"])
+
+
 def flops_forward(N, Nother, Nstc, Ndyn):
     """Algorithmic flops of one psi evaluation; cost+gradient is counted as 3x."""
     return N * (33 + 8 * (2 * Nother - 1) + 28 * Nstc + 62 * Ndyn) + 10 * N * (N + 1) + 12 * N
@@ -166,7 +183,8 @@ def main():
                        "np": layout.np_, "sharding": f"{world} x independent shards, all_gather of U"
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved_gbs / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(args.workload, args.dtype, B),
                          "kernel": "solve_kernel<float,3>" if args.dtype == "f32" else "solve_kernel<double,3>",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_per_solve * B,
                          "valu": {"achieved": achieved_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
