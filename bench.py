@@ -90,8 +90,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the solver has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ      # under torch.distributed.run the same path runs for N = 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
 
     desc, key = WORKLOADS[args.workload]
@@ -119,20 +121,20 @@ def main():
     dstatus = torch.empty(B, dtype=torch.int32, device="cuda")
     diters = torch.empty(B, 2, dtype=torch.int32, device="cuda")
     dinfo = torch.empty(B, 8, dtype=t_dtype, device="cuda")
-    gathered = torch.empty(world * B, 2 * N, dtype=t_dtype, device="cuda") if world > 1 else None
+    gathered = torch.empty(world * B, 2 * N, dtype=t_dtype, device="cuda") if use_dist else None
 
     kernel_ms = []
 
     def step(record):
         h.solve_raw(np_dtype, dP, B, dU, dcost, dstatus, diters, None, None, False, None, dinfo, sync=False)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, dU)      # RCCL over xGMI: gather the results, nothing else
         if record:
             kernel_ms.append(h.last_kernel_ms())           # HIP events on the launch stream (syncs that stream)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -144,7 +146,7 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -200,7 +202,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     h.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -75,11 +75,15 @@ bool is_device_ptr(const void* ptr)
 struct Layout {
     int np, off_rs, off_rv, off_c0, off_c, off_os, off_od, off_qstc, off_qdyn;
     int lds_alpha, lds_poly, lds_seg, lds_seginv, lds_fl0, lds_fl, lds_iflag, lds_hist, lds_rho, lds_total;
+    bool glb;             // obstacle table streamed from a global workspace instead of LDS
+    long long ws_stride;  // workspace elements per instance (glb only)
 };
+
+constexpr size_t kLdsLimit = 160 * 1024; // bytes of LDS one workgroup may use on gfx950
 
 int round4(int x) { return (x + 3) & ~3; }
 
-Layout make_layout(const nmpc_config& c)
+Layout make_layout(const nmpc_config& c, size_t elem_size)
 {
     Layout L;
     const int N = c.N_hor;
@@ -93,8 +97,11 @@ Layout make_layout(const nmpc_config& c)
     L.off_qdyn = L.off_qstc + N;
     L.np = L.off_qdyn + N;
     const int ne = c.Ndynobs * (N + 1);
-    L.lds_alpha = nmpc::kEllStride * ne;
-    L.lds_poly = L.lds_alpha + round4(ne);
+    L.glb = false;
+    L.ws_stride = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    L.lds_alpha = L.glb ? 0 : nmpc::kEllStride * ne;
+    L.lds_poly = L.lds_alpha + (L.glb ? 0 : round4(ne));
     L.lds_seg = L.lds_poly + 12 * c.Nstcobs;
     L.lds_seginv = L.lds_seg + 4 * N;
     L.lds_fl0 = L.lds_seginv + round4(N);
@@ -103,6 +110,10 @@ Layout make_layout(const nmpc_config& c)
     L.lds_hist = L.lds_iflag + round4(c.Ndynobs);  // int flags / compaction map (an int fits in a T)
     L.lds_rho = L.lds_hist + 4 * nmpc::kMem * N;    // L-BFGS ring: kMem x N x (s_v, s_w, y_v, y_w)
     L.lds_total = L.lds_rho + round4(2 * nmpc::kMem); // rho[kMem], alpha[kMem]
+    if (L.glb || (size_t)L.lds_total * elem_size <= kLdsLimit) break;
+    L.glb = true; // second attempt: everything but the ellipse table in LDS
+    L.ws_stride = (long long)(nmpc::kEllStride + 1) * ne;
+    }
     return L;
 }
 
@@ -110,13 +121,18 @@ Layout make_layout(const nmpc_config& c)
 
 struct nmpc_handle_s {
     nmpc_config cfg;
-    Layout lay;
+    Layout lay32, lay64;
     int lps;
+    template <typename T>
+    const Layout& lay() const
+    {
+        return sizeof(T) == 4 ? lay32 : lay64;
+    }
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    DevBuf dP, dU, dcost, dstatus, diters, du0, dy, dc0, dinfo, dY2, dC2, dpsi, dgrad, df2;
+    DevBuf dP, dU, dcost, dstatus, diters, du0, dy, dc0, dinfo, dY2, dC2, dpsi, dgrad, df2, dws;
 };
 
 namespace {
@@ -128,19 +144,20 @@ namespace {
 #ifndef NMPC_WPE_F64
 #define NMPC_WPE_F64 1
 #endif
-template <typename T, int LPS>
+template <typename T, int LPS, bool GLB>
 __global__ __launch_bounds__(64, (sizeof(T) == 4 ? NMPC_WPE_F32 : NMPC_WPE_F64)) void solve_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    nmpc::solve_instance<T, LPS>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
+    nmpc::solve_instance<T, LPS, GLB>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
 }
 
-template <typename T, int LPS>
+template <typename T, int LPS, bool GLB>
 __global__ __launch_bounds__(64) void eval_kernel(nmpc::KParams<T> kp, nmpc::EvalParams<T> ep)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int inst = blockIdx.x, N = kp.N;
-    nmpc::Instance<T, LPS> I(kp, kp.P + (size_t)inst * kp.np, reinterpret_cast<T*>(smem));
+    nmpc::Instance<T, LPS, GLB> I(kp, kp.P + (size_t)inst * kp.np, reinterpret_cast<T*>(smem),
+                                  GLB ? kp.ws + (long long)inst * kp.ws_stride : nullptr);
     I.load();
     const int kk = I.act ? I.k : 0;
     T v = ep.U[(size_t)inst * 2 * N + 2 * kk], w = ep.U[(size_t)inst * 2 * N + 2 * kk + 1];
@@ -201,7 +218,7 @@ template <typename T>
 void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k)
 {
     const nmpc_config& c = h->cfg;
-    const Layout& L = h->lay;
+    const Layout& L = h->lay<T>();
     std::memset(&k, 0, sizeof k);
     k.N = c.N_hor;
     k.Nother = c.Nother;
@@ -261,14 +278,16 @@ template <typename T>
 using EvalFn = void (*)(nmpc::KParams<T>, nmpc::EvalParams<T>);
 
 template <typename T>
-SolveFn<T> pick_solve(int lps)
+SolveFn<T> pick_solve(int lps, bool glb)
 {
-    return lps == 3 ? solve_kernel<T, 3> : lps == 2 ? solve_kernel<T, 2> : solve_kernel<T, 1>;
+    if (glb) return lps == 3 ? solve_kernel<T, 3, true> : lps == 2 ? solve_kernel<T, 2, true> : solve_kernel<T, 1, true>;
+    return lps == 3 ? solve_kernel<T, 3, false> : lps == 2 ? solve_kernel<T, 2, false> : solve_kernel<T, 1, false>;
 }
 template <typename T>
-EvalFn<T> pick_eval(int lps)
+EvalFn<T> pick_eval(int lps, bool glb)
 {
-    return lps == 3 ? eval_kernel<T, 3> : lps == 2 ? eval_kernel<T, 2> : eval_kernel<T, 1>;
+    if (glb) return lps == 3 ? eval_kernel<T, 3, true> : lps == 2 ? eval_kernel<T, 2, true> : eval_kernel<T, 1, true>;
+    return lps == 3 ? eval_kernel<T, 3, false> : lps == 2 ? eval_kernel<T, 2, false> : eval_kernel<T, 1, false>;
 }
 
 // stage `count` elements: returns the device pointer to use (src itself if already on the device)
@@ -315,11 +334,17 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
     if (B < 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "B = %d < 0", B);
     if (B == 0) return 0;
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    const size_t n = 2 * (size_t)h->cfg.N_hor, np = h->lay.np;
+    const Layout& L = h->lay<T>();
+    const size_t n = 2 * (size_t)h->cfg.N_hor, np = L.np;
     nmpc::KParams<T> k;
     fill_kparams(h, k);
     k.B = B;
     k.y_is_input = y_is_input;
+    if (L.glb) {
+        if (int rc_ = h->dws.reserve((size_t)B * L.ws_stride * sizeof(T))) return rc_;
+        k.ws = static_cast<T*>(h->dws.p);
+        k.ws_stride = L.ws_stride;
+    }
     bool hU, hcost, hstatus, hiters, hy, hinfo;
     int rc;
     if ((rc = stage_in(h, h->dP, P, (size_t)B * np, &k.P))) return rc;
@@ -334,8 +359,8 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
     if ((rc = stage_out(h->dinfo, info, (size_t)B * info_row, &k.info, &hinfo))) return rc;
     if (hy && y_is_input) HIP_TRY(hipMemcpyAsync(k.y, y, (size_t)B * n * sizeof(T), hipMemcpyHostToDevice, h->stream));
 
-    const size_t lds_bytes = (size_t)h->lay.lds_total * sizeof(T);
-    SolveFn<T> fn = pick_solve<T>(h->lps);
+    const size_t lds_bytes = (size_t)L.lds_total * sizeof(T);
+    SolveFn<T> fn = pick_solve<T>(h->lps, L.glb);
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(fn, dim3(B), dim3(64), lds_bytes, h->stream, k);
     HIP_TRY(hipGetLastError());
@@ -364,10 +389,16 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
     if (!P || !U || !Y || !C || !psi) return fail(NMPC_ERR_INVALID_ARGUMENT, "P, U, Y, C, psi must not be NULL");
     if (B <= 0) return B == 0 ? 0 : fail(NMPC_ERR_INVALID_ARGUMENT, "B = %d < 0", B);
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    const size_t n = 2 * (size_t)h->cfg.N_hor, np = h->lay.np;
+    const Layout& L = h->lay<T>();
+    const size_t n = 2 * (size_t)h->cfg.N_hor, np = L.np;
     nmpc::KParams<T> k;
     fill_kparams(h, k);
     k.B = B;
+    if (L.glb) {
+        if (int rc_ = h->dws.reserve((size_t)B * L.ws_stride * sizeof(T))) return rc_;
+        k.ws = static_cast<T*>(h->dws.p);
+        k.ws_stride = L.ws_stride;
+    }
     nmpc::EvalParams<T> ep;
     bool hpsi, hgrad, hf2;
     int rc;
@@ -378,8 +409,8 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
     if ((rc = stage_out(h->dpsi, psi, (size_t)B, &ep.psi, &hpsi))) return rc;
     if ((rc = stage_out(h->dgrad, grad, (size_t)B * n, &ep.grad, &hgrad))) return rc;
     if ((rc = stage_out(h->df2, f2sq, (size_t)B, &ep.f2sq, &hf2))) return rc;
-    const size_t lds_bytes = (size_t)h->lay.lds_total * sizeof(T);
-    EvalFn<T> fn = pick_eval<T>(h->lps);
+    const size_t lds_bytes = (size_t)L.lds_total * sizeof(T);
+    EvalFn<T> fn = pick_eval<T>(h->lps, L.glb);
     hipLaunchKernelGGL(fn, dim3(B), dim3(64), lds_bytes, h->stream, k, ep);
     HIP_TRY(hipGetLastError());
     if (hpsi) HIP_TRY(hipMemcpyAsync(psi, ep.psi, (size_t)B * sizeof(T), hipMemcpyDeviceToHost, h->stream));
@@ -392,11 +423,12 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
 template <typename T>
 int set_lds_limit(nmpc_handle_s* h)
 {
-    const size_t lds_bytes = (size_t)h->lay.lds_total * sizeof(T);
+    const Layout& L = h->lay<T>();
+    const size_t lds_bytes = (size_t)L.lds_total * sizeof(T);
     if (lds_bytes > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve<T>(h->lps)),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve<T>(h->lps, L.glb)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_eval<T>(h->lps)),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_eval<T>(h->lps, L.glb)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
     return 0;
@@ -477,20 +509,17 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
     nmpc_handle_s* h = new (std::nothrow) nmpc_handle_s();
     if (!h) return fail(NMPC_ERR_OUT_OF_MEMORY, "host allocation failed");
     h->cfg = *cfg;
-    h->lay = make_layout(*cfg);
+    h->lay32 = make_layout(*cfg, sizeof(float));
+    h->lay64 = make_layout(*cfg, sizeof(double));
     h->lps = 64 / cfg->N_hor;
     if (h->lps > 3) h->lps = 3;
     if (h->lps < 1) h->lps = 1;
-    const size_t lds64 = (size_t)h->lay.lds_total * sizeof(double);
-    const size_t lds32 = (size_t)h->lay.lds_total * sizeof(float);
-    if (lds32 > 160 * 1024) {
+    if ((size_t)h->lay64.lds_total * sizeof(double) > kLdsLimit || (size_t)h->lay32.lds_total * sizeof(float) > kLdsLimit) {
+        const size_t need = (size_t)h->lay64.lds_total * sizeof(double);
         delete h;
         return fail(NMPC_ERR_UNSUPPORTED,
-                    "obstacle tables need %zu B of LDS per instance (> 160 KiB): this configuration needs the "
-                    "HBM-streaming kernel, which is not built yet",
-                    lds32);
+                    "polygon / robot / path tables alone need %zu B of LDS per instance (> 160 KiB)", need);
     }
-    (void)lds64;
     hipError_t e = hipSetDevice(cfg->device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
@@ -501,7 +530,7 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
     }
     h->stream = h->own_stream;
     int rc = set_lds_limit<float>(h);
-    if (rc == 0 && lds64 <= 160 * 1024) rc = set_lds_limit<double>(h);
+    if (rc == 0) rc = set_lds_limit<double>(h);
     if (rc) {
         nmpc_destroy(h);
         return rc;
@@ -516,7 +545,7 @@ int nmpc_destroy(nmpc_handle h)
     (void)hipSetDevice(h->cfg.device_id);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (DevBuf* b : {&h->dP, &h->dU, &h->dcost, &h->dstatus, &h->diters, &h->du0, &h->dy, &h->dc0, &h->dinfo,
-                      &h->dY2, &h->dC2, &h->dpsi, &h->dgrad, &h->df2})
+                      &h->dY2, &h->dC2, &h->dpsi, &h->dgrad, &h->df2, &h->dws})
         b->release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -528,7 +557,7 @@ int nmpc_destroy(nmpc_handle h)
 int nmpc_param_len(nmpc_handle h)
 {
     if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
-    return h->lay.np;
+    return h->lay32.np;
 }
 
 int nmpc_set_stream(nmpc_handle h, void* s)
@@ -549,8 +578,6 @@ int nmpc_solve_batch_f64(nmpc_handle h, const double* P, int32_t B, double* U, d
                          int32_t* iters, const double* u0, double* y, int32_t y_is_input, const double* c0,
                          double* info, int32_t sync)
 {
-    if (h && (size_t)h->lay.lds_total * sizeof(double) > 160 * 1024)
-        return fail(NMPC_ERR_UNSUPPORTED, "f64 tables exceed 160 KiB of LDS for this configuration");
     return solve_batch<double>(h, P, B, U, cost, status, iters, u0, y, y_is_input, c0, info, sync);
 }
 
@@ -563,8 +590,6 @@ int nmpc_eval_batch_f32(nmpc_handle h, const float* P, const float* U, const flo
 int nmpc_eval_batch_f64(nmpc_handle h, const double* P, const double* U, const double* Y, const double* C, int32_t B,
                         double* psi, double* grad, double* f2sq)
 {
-    if (h && (size_t)h->lay.lds_total * sizeof(double) > 160 * 1024)
-        return fail(NMPC_ERR_UNSUPPORTED, "f64 tables exceed 160 KiB of LDS for this configuration");
     return eval_batch<double>(h, P, U, Y, C, B, psi, grad, f2sq);
 }
 
@@ -582,21 +607,20 @@ int nmpc_kernel_info(nmpc_handle h, int32_t* lds_bytes_f32, int32_t* lds_bytes_f
 {
     if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    const size_t l32 = (size_t)h->lay.lds_total * 4, l64 = (size_t)h->lay.lds_total * 8;
+    const size_t l32 = (size_t)h->lay32.lds_total * 4, l64 = (size_t)h->lay64.lds_total * 8;
     if (lds_bytes_f32) *lds_bytes_f32 = (int32_t)l32;
     if (lds_bytes_f64) *lds_bytes_f64 = (int32_t)l64;
     if (lanes_per_step) *lanes_per_step = h->lps;
     if (waves_per_cu_f32) {
         int nb = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &nb, reinterpret_cast<const void*>(pick_solve<float>(h->lps)), 64, l32));
+            &nb, reinterpret_cast<const void*>(pick_solve<float>(h->lps, h->lay32.glb)), 64, l32));
         *waves_per_cu_f32 = nb;
     }
     if (waves_per_cu_f64) {
         int nb = 0;
-        if (l64 <= 160 * 1024)
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                &nb, reinterpret_cast<const void*>(pick_solve<double>(h->lps)), 64, l64));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &nb, reinterpret_cast<const void*>(pick_solve<double>(h->lps, h->lay64.glb)), 64, l64));
         *waves_per_cu_f64 = nb;
     }
     return 0;
