@@ -110,6 +110,9 @@ def main():
     cfg = nm.default_config_struct()
     cfg.device_id = local_rank
     cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs = layout.N, layout.Nother, layout.Nstc, layout.Ndyn
+    # capacity hint: the workload has n_ped x n_hyp predicted-obstacle hypotheses, the remaining Ndynobs slots are
+    # the reference's zero padding (mpc_interface.py:82-88); fewer provisioned rows -> less LDS per instance
+    cfg.max_active_dynobs = spec["n_ped"] * spec["n_hyp"]
     h = nm.Handle(cfg)
     stream = torch.cuda.current_stream()
     h.set_stream(stream.cuda_stream)
@@ -182,7 +185,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "batch_per_gpu": B, "N_hor": layout.N,
                        "Ndynobs": layout.Ndyn, "Nstcobs": layout.Nstc, "Nother": layout.Nother,
-                       "np": layout.np_, "sharding": f"{world} x independent shards, all_gather of U"
+                       "np": layout.np_, "max_active_dynobs": int(cfg.max_active_dynobs), "sharding": f"{world} x independent shards, all_gather of U"
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS,

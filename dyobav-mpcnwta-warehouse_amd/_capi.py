@@ -13,7 +13,8 @@ import numpy as np
 
 from . import build as _build
 
-EXIT_STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotFiniteComputation")
+EXIT_STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotFiniteComputation",
+                     "CapacityExceeded")
 ABI_VERSION = 1
 
 
@@ -34,7 +35,7 @@ class NmpcConfigStruct(C.Structure):
         ("vehicle_width", C.c_double), ("vehicle_margin", C.c_double), ("social_margin", C.c_double),
         ("tolerance", C.c_double), ("initial_tolerance", C.c_double), ("delta_tolerance", C.c_double),
         ("max_outer_iterations", C.c_int32), ("max_inner_iterations", C.c_int32),
-        ("lbfgs_memory", C.c_int32), ("reserved0", C.c_int32),
+        ("lbfgs_memory", C.c_int32), ("max_active_dynobs", C.c_int32),
         ("initial_penalty", C.c_double), ("penalty_update_factor", C.c_double),
         ("inner_tolerance_update_factor", C.c_double), ("sufficient_decrease_coeff", C.c_double),
         ("lip_eps_f64", C.c_double), ("lip_delta_f64", C.c_double),

@@ -75,6 +75,7 @@ bool is_device_ptr(const void* ptr)
 struct Layout {
     int np, off_rs, off_rv, off_c0, off_c, off_os, off_od, off_qstc, off_qdyn;
     int lds_alpha, lds_poly, lds_seg, lds_seginv, lds_fl0, lds_fl, lds_iflag, lds_hist, lds_rho, lds_total;
+    int dyn_cap;          // obstacle rows provisioned per instance
     bool glb;             // obstacle table streamed from a global workspace instead of LDS
     long long ws_stride;  // workspace elements per instance (glb only)
 };
@@ -96,7 +97,9 @@ Layout make_layout(const nmpc_config& c, size_t elem_size)
     L.off_qstc = L.off_od + 6 * (N + 1) * c.Ndynobs;
     L.off_qdyn = L.off_qstc + N;
     L.np = L.off_qdyn + N;
-    const int ne = c.Ndynobs * (N + 1);
+    const int cap = c.max_active_dynobs > 0 && c.max_active_dynobs < c.Ndynobs ? c.max_active_dynobs : c.Ndynobs;
+    const int ne = cap * (N + 1); // rows provisioned in LDS / the workspace
+    L.dyn_cap = cap;
     L.glb = false;
     L.ws_stride = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -105,8 +108,8 @@ Layout make_layout(const nmpc_config& c, size_t elem_size)
     L.lds_seg = L.lds_poly + 12 * c.Nstcobs;
     L.lds_seginv = L.lds_seg + 4 * N;
     L.lds_fl0 = L.lds_seginv + round4(N);
-    L.lds_fl = L.lds_fl0 + round4(2 * c.Nother);
-    L.lds_iflag = L.lds_fl + round4(2 * c.Nother * N);
+    L.lds_fl = L.lds_fl0 + round4(c.Nother);          // int list: robots with a non-zero t=0 position
+    L.lds_iflag = L.lds_fl + round4(c.Nother);         // int list: robots with a non-zero predicted position
     L.lds_hist = L.lds_iflag + round4(c.Ndynobs);  // int flags / compaction map (an int fits in a T)
     L.lds_rho = L.lds_hist + 4 * nmpc::kMem * N;    // L-BFGS ring: kMem x N x (s_v, s_w, y_v, y_w)
     L.lds_total = L.lds_rho + round4(2 * nmpc::kMem); // rho[kMem], alpha[kMem]
@@ -158,7 +161,10 @@ __global__ __launch_bounds__(64) void eval_kernel(nmpc::KParams<T> kp, nmpc::Eva
     const int inst = blockIdx.x, N = kp.N;
     nmpc::Instance<T, LPS, GLB> I(kp, kp.P + (size_t)inst * kp.np, reinterpret_cast<T*>(smem),
                                   GLB ? kp.ws + (long long)inst * kp.ws_stride : nullptr);
-    I.load();
+    if (!I.load()) {
+        if (I.lane == 0) ep.psi[inst] = __builtin_nanf("");
+        return;
+    }
     const int kk = I.act ? I.k : 0;
     T v = ep.U[(size_t)inst * 2 * N + 2 * kk], w = ep.U[(size_t)inst * 2 * N + 2 * kk + 1];
     T yv = ep.Y[(size_t)inst * 2 * N + kk], yw = ep.Y[(size_t)inst * 2 * N + N + kk];
@@ -225,6 +231,7 @@ void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k)
     k.Nstc = c.Nstcobs;
     k.Ndyn = c.Ndynobs;
     k.np = L.np;
+    k.dyn_cap = L.dyn_cap;
     k.off_rs = L.off_rs;
     k.off_rv = L.off_rv;
     k.off_c0 = L.off_c0;
@@ -467,6 +474,7 @@ int nmpc_default_config(nmpc_config* c)
     c->max_outer_iterations = 10;
     c->max_inner_iterations = 500;
     c->lbfgs_memory = 10;
+    c->max_active_dynobs = 0;
     c->initial_penalty = 10.0;
     c->penalty_update_factor = 5.0;
     c->inner_tolerance_update_factor = 0.1;
@@ -493,6 +501,8 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
     if (cfg->Nother < 1 || cfg->Nstcobs < 0 || cfg->Ndynobs < 0)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "bad dimensions Nother=%d Nstcobs=%d Ndynobs=%d", cfg->Nother,
                     cfg->Nstcobs, cfg->Ndynobs);
+    if (cfg->max_active_dynobs < 0)
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "max_active_dynobs = %d < 0", cfg->max_active_dynobs);
     if (cfg->lbfgs_memory < 1 || cfg->lbfgs_memory > NMPC_LBFGS_MAX_MEMORY)
         return fail(NMPC_ERR_UNSUPPORTED, "lbfgs_memory = %d outside [1, %d]", cfg->lbfgs_memory,
                     NMPC_LBFGS_MAX_MEMORY);

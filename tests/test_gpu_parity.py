@@ -8,6 +8,8 @@ Tolerances (stated per test):
     differ by ~1e-3 between ANY two floating-point evaluation orders (measured; DESIGN.md "parity protocol"),
     so full-solve parity is asserted with the step set to 1e-4 on both sides and reported as fractions.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -285,3 +287,35 @@ def test_fp32_vs_fp64_tolerance_sweep_long_horizon():
     # measured on MI355X: 0.125 / 0.0127 / 0.0018 -- the distance scales with the tolerance (error ~ tol / gamma)
     assert med[1e-3] < 0.3 and med[1e-4] < 0.04 and med[1e-5] < 0.006, med
     assert med[1e-5] < med[1e-4] < med[1e-3], med
+
+
+def test_capacity_hint_same_results_and_safe_failure():
+    """nmpc_config.max_active_dynobs: provisioning exactly the non-zero obstacle slots changes nothing; provisioning
+    fewer makes the instance fail loudly (status 4 = CapacityExceeded, NaN controls) instead of reading past the table."""
+    L = nm.scenarios.ParamLayout()
+    P = nm.scenarios.make_batch(96, L, seed=41, n_ped=2, n_hyp=5).astype(np.float32)      # 10 of 15 slots used
+    pr = oracle.Problem()
+    with nm.Handle(config_for(pr)) as h:
+        full = h.solve(P)
+        lds_full = h.kernel_info()["lds_bytes_f32"]
+    with nm.Handle(config_for(pr, max_active_dynobs=10)) as h:
+        hint = h.solve(P)
+        assert h.kernel_info()["lds_bytes_f32"] < lds_full
+    assert np.array_equal(hint["U"], full["U"]) and np.array_equal(hint["status"], full["status"])
+    assert np.array_equal(hint["iters"], full["iters"])
+    with nm.Handle(config_for(pr, max_active_dynobs=9)) as h:
+        small = h.solve(P)
+    assert (small["status"] == 4).all() and np.isnan(small["U"]).all()
+    P2 = P.copy()
+    P2[:48, L.od + 9 * 21 * 6: L.od + 10 * 21 * 6] = 0.0        # first half: only 9 non-zero slots
+    with nm.Handle(config_for(pr, max_active_dynobs=9)) as h:
+        mixed = h.solve(P2)
+    assert (mixed["status"][:48] <= 1).all() and (mixed["status"][48:] == 4).all()
+    assert np.isfinite(mixed["U"][:48]).all()
+
+
+def test_other_robots_nonzero_paths():
+    """Non-zero other-robot slots (fleet terms) are read from the parameter vector through the LDS index lists."""
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "problem_n20.npz"))
+    L = nm.scenarios.ParamLayout()
+    assert (fx["P"][:, L.c0:L.c0 + 30] != 0).any() and (fx["P"][:, L.c:L.c + 600] != 0).any()

@@ -6,7 +6,7 @@ os.environ["NMPC_HIP_LIBRARY"] = os.path.join(os.path.dirname(os.path.dirname(os
 import numpy as np
 import dyobav_mpcnwta_warehouse_amd as nm
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-h = nm.Handle(nm.default_config_struct())
+cfg = nm.default_config_struct(); cfg.lbfgs_memory = int(os.environ.get("LBFGS_MEM", "10")); h = nm.Handle(cfg)
 L = nm.scenarios.ParamLayout()
 P = nm.scenarios.make_batch(B, L, seed=0).astype(np.float32)
 U = np.empty((B, 40), np.float32); info = np.empty((B, 24), np.float32)
