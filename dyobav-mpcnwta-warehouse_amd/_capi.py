@@ -44,10 +44,19 @@ class NmpcConfigStruct(C.Structure):
     ]
 
 
+class NmpcAssembleArgs(C.Structure):
+    """Mirror of ``struct nmpc_assemble_args`` (device pointers)."""
+    _fields_ = [("last_u", C.c_void_p), ("state", C.c_void_p), ("ref_states", C.c_void_p), ("speed_ref", C.c_void_p),
+                ("tuning", C.c_void_p), ("other_robots", C.c_void_p), ("map_polygons", C.c_void_p),
+                ("n_map_polygons", C.c_int32), ("n_dyn", C.c_int32), ("dyn_obstacles", C.c_void_p),
+                ("stc_weights", C.c_void_p), ("dyn_weights", C.c_void_p)]
+
+
 # every symbol include/nmpc_hip.h declares (checked by the CPU test-suite against the built library)
 EXPORTED_SYMBOLS = (
     "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_param_len", "nmpc_set_stream",
     "nmpc_solve_batch_f32", "nmpc_solve_batch_f64", "nmpc_eval_batch_f32", "nmpc_eval_batch_f64",
+    "nmpc_assemble_params_f32", "nmpc_assemble_params_f64",
     "nmpc_last_kernel_ms", "nmpc_kernel_info", "nmpc_selftest", "nmpc_last_error",
 )
 
@@ -87,6 +96,7 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     for sfx in ("f32", "f64"):
         getattr(lib, "nmpc_solve_batch_" + sfx).argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32]
         getattr(lib, "nmpc_eval_batch_" + sfx).argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp]
+        getattr(lib, "nmpc_assemble_params_" + sfx).argtypes = [vp, C.POINTER(NmpcAssembleArgs), i32, vp]
     lib.nmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.nmpc_kernel_info.argtypes = [vp] + [C.POINTER(i32)] * 5
     lib.nmpc_selftest.argtypes = [vp]
@@ -189,6 +199,22 @@ class Handle:
         p = _Arg.ptr
         _check(fn(self._h, p(P), int(B), p(U), p(cost), p(status), p(iters), p(u0), p(y), int(bool(y_is_input)),
                   p(c0), p(info), int(bool(sync))))
+
+    def assemble_params(self, dtype, B, P_out, last_u, state, ref_states, speed_ref, tuning, stc_weights, dyn_weights,
+                        map_polygons=None, dyn_obstacles=None, other_robots=None):
+        """``nmpc_assemble_params_*``: device tensors in (torch / raw pointers), ``P_out[B, np]`` written on the
+        handle's stream. ``map_polygons`` [M,4,2]; ``dyn_obstacles`` [B,n_dyn,N+1,6]."""
+        a = NmpcAssembleArgs()
+        p = _Arg.ptr
+        a.last_u, a.state, a.ref_states, a.speed_ref = p(last_u), p(state), p(ref_states), p(speed_ref)
+        a.tuning, a.stc_weights, a.dyn_weights = p(tuning), p(stc_weights), p(dyn_weights)
+        a.other_robots = p(other_robots)
+        a.map_polygons = p(map_polygons)
+        a.n_map_polygons = 0 if map_polygons is None else int(map_polygons.shape[0])
+        a.dyn_obstacles = p(dyn_obstacles)
+        a.n_dyn = 0 if dyn_obstacles is None else int(dyn_obstacles.shape[1])
+        fn = getattr(self._lib, "nmpc_assemble_params_" + _suffix(dtype))
+        _check(fn(self._h, C.byref(a), int(B), p(P_out)))
 
     def solve(self, P: np.ndarray, u0=None, y0=None, c0=None, dtype=None, want_info=True) -> dict:
         """Solve a batch held in host memory; returns numpy arrays."""

@@ -4,6 +4,7 @@
 // either launches the HIP kernels or returns an error code.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -12,6 +13,7 @@
 #include <vector>
 
 #include "../../include/nmpc_hip.h"
+#include "nmpc_assemble.h"
 #include "nmpc_device.h"
 
 namespace {
@@ -428,6 +430,66 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
 }
 
 template <typename T>
+int assemble_params(nmpc_handle_s* h, const nmpc_assemble_args* g, int32_t B, T* P)
+{
+    if (!h || !g || !P) return fail(NMPC_ERR_INVALID_ARGUMENT, "null argument");
+    if (B <= 0) return B == 0 ? 0 : fail(NMPC_ERR_INVALID_ARGUMENT, "B = %d < 0", B);
+    const nmpc_config& c = h->cfg;
+    if (g->n_dyn < 0 || g->n_dyn > c.Ndynobs)
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "n_dyn = %d outside [0, Ndynobs = %d]", g->n_dyn, c.Ndynobs);
+    if (g->n_map_polygons < 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "n_map_polygons < 0");
+    const void* required[] = {g->last_u, g->state, g->ref_states, g->speed_ref, g->tuning, g->stc_weights,
+                              g->dyn_weights, P};
+    for (const void* q : required)
+        if (!is_device_ptr(q))
+            return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_assemble_params: every array must be a device pointer");
+    if ((g->n_map_polygons > 0 && !is_device_ptr(g->map_polygons)) || (g->n_dyn > 0 && !is_device_ptr(g->dyn_obstacles)) ||
+        (g->other_robots && !is_device_ptr(g->other_robots)))
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_assemble_params: every array must be a device pointer");
+    HIP_TRY(hipSetDevice(c.device_id));
+    const Layout& L = h->lay<T>();
+    nmpc::AsmParams<T> a;
+    std::memset(&a, 0, sizeof a);
+    a.N = c.N_hor;
+    a.Nother = c.Nother;
+    a.Nstc = c.Nstcobs;
+    a.Ndyn = c.Ndynobs;
+    a.np = L.np;
+    a.off_rs = L.off_rs;
+    a.off_rv = L.off_rv;
+    a.off_c0 = L.off_c0;
+    a.off_os = L.off_os;
+    a.off_od = L.off_od;
+    a.off_qstc = L.off_qstc;
+    a.off_qdyn = L.off_qdyn;
+    a.B = B;
+    a.M = g->n_map_polygons;
+    a.n_dyn = g->n_dyn;
+    a.last_u = static_cast<const T*>(g->last_u);
+    a.state = static_cast<const T*>(g->state);
+    a.ref_states = static_cast<const T*>(g->ref_states);
+    a.speed_ref = static_cast<const T*>(g->speed_ref);
+    a.tuning = static_cast<const T*>(g->tuning);
+    a.other_robots = static_cast<const T*>(g->other_robots);
+    a.map_polygons = static_cast<const T*>(g->map_polygons);
+    a.dyn = g->n_dyn > 0 ? static_cast<const T*>(g->dyn_obstacles) : nullptr;
+    a.stc_weights = static_cast<const T*>(g->stc_weights);
+    a.dyn_weights = static_cast<const T*>(g->dyn_weights);
+    a.P = P;
+    const size_t lds = (size_t)a.M * sizeof(T) + (size_t)a.Nstc * sizeof(int) + 16;
+    if (lds > kLdsLimit) return fail(NMPC_ERR_UNSUPPORTED, "%d map polygons do not fit the selection kernel's LDS", a.M);
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(nmpc::select_static_kernel<T>, dim3(B), dim3(64), lds, h->stream, a);
+    const size_t nquad = ((size_t)B * a.np + 3) / 4;
+    const int blocks = (int)std::min<size_t>((nquad + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(nmpc::fill_kernel<T>, dim3(blocks), dim3(256), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return 0;
+}
+
+template <typename T>
 int set_lds_limit(nmpc_handle_s* h)
 {
     const Layout& L = h->lay<T>();
@@ -601,6 +663,16 @@ int nmpc_eval_batch_f64(nmpc_handle h, const double* P, const double* U, const d
                         double* psi, double* grad, double* f2sq)
 {
     return eval_batch<double>(h, P, U, Y, C, B, psi, grad, f2sq);
+}
+
+int nmpc_assemble_params_f32(nmpc_handle h, const nmpc_assemble_args* args, int32_t B, float* P)
+{
+    return assemble_params<float>(h, args, B, P);
+}
+
+int nmpc_assemble_params_f64(nmpc_handle h, const nmpc_assemble_args* args, int32_t B, double* P)
+{
+    return assemble_params<double>(h, args, B, P);
 }
 
 int nmpc_last_kernel_ms(nmpc_handle h, float* ms)

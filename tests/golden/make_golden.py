@@ -16,6 +16,8 @@ Fixtures written:
   motion_model.npz     unicycle_model RK4 (basic_motion_model/motion_model.py:141-163) on random states/actions.
   tracker_harness.json parameter lists / return values of TrajectoryTracker.run_step
                        (pkg_mpc_tracker/trajectory_tracker.py:273-383) driven by a scripted fake solver.
+  assemble_cases.json  inputs and the resulting parameter vector of MpcInterface.run_step
+                       (interfaces/mpc_interface.py:52-100: closest-N polygons -> half-spaces, obstacle flattening).
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -344,6 +346,76 @@ def main():
         json.dump(th, fh)
     print("tracker_harness.json:", len(th["steps"]), "steps, len(p) =", len(th["steps"][0]["params"]))
 
+    ac = assemble_fixture()
+    with open(os.path.join(HERE, "assemble_cases.json"), "w") as fh:
+        json.dump(ac, fh)
+    print("assemble_cases.json:", len(ac), "cases")
+
 
 if __name__ == "__main__":
     main()
+
+
+# ---------------------------------------------------------------------------------------------------------
+def assemble_fixture(K=6, seed=77):
+    """f1 ("next" row): drive the reference's MpcInterface.run_step (interfaces/mpc_interface.py:52-100) -- closest-N
+    static polygons -> half-spaces (pkg_mpc_tracker/utils_geo.py), dynamic-obstacle flattening, and the tracker's
+    parameter concatenation -- with a fake solver and record inputs + the parameter vector it hands to the solver.
+    basic_map.* (pyclipper / skimage, absent here) is only used for type hints in that file and is stubbed."""
+    for name in ("basic_map", "basic_map.map_geometric", "basic_map.graph_basic"):
+        m = types.ModuleType(name)
+        m.GeometricMap = object
+        m.NetGraph = object
+        m.__path__ = []
+        sys.modules.setdefault(name, m)
+    solver_dir = tempfile.mkdtemp(prefix="fake_mpc_solver2_")
+    os.makedirs(os.path.join(solver_dir, "mpc_solver", "navi_fast"))
+    with open(os.path.join(solver_dir, "mpc_solver", "navi_fast", "navi_fast.py"), "w") as fh:
+        fh.write("import types\nCALLS = []\nclass _S:\n"
+                 "    def run(self, p, *a, **k):\n"
+                 "        CALLS.append([float(v) for v in p])\n"
+                 "        return types.SimpleNamespace(solution=[0.3, 0.05] * 20, cost=1.0, exit_status='Converged',\n"
+                 "                                     solve_time_ms=1.0)\n"
+                 "def solver():\n    return _S()\n")
+    sys.modules.pop("navi_fast", None)
+    cwd = os.getcwd()
+    os.chdir(solver_dir)
+    rng = np.random.default_rng(seed)
+    cases = []
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            from interfaces.mpc_interface import MpcInterface
+        for _ in range(K):
+            M = int(rng.integers(12, 40))
+            polys = []
+            for _m in range(M):
+                c = rng.uniform(-8, 8, 2)
+                hx, hy = rng.uniform(0.3, 1.5, 2)
+                ang = rng.uniform(-np.pi, np.pi)
+                R = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+                corners = np.array([[hx, hy], [-hx, hy], [-hx, -hy], [hx, -hy]]) @ R.T + c
+                polys.append([tuple(map(float, v)) for v in corners])
+            geo = types.SimpleNamespace(processed_obstacle_list=polys)
+            state = np.array([rng.uniform(-6, 6), rng.uniform(-6, 6), rng.uniform(-3, 3)])
+            with contextlib.redirect_stdout(io.StringIO()):
+                mi = MpcInterface("mpc_fast.yaml", state, geo, verbose=False)
+            goal = (float(state[0] + 7.0), float(state[1] + 2.0))
+            mi.update_global_path([goal])
+            n_obs = int(rng.integers(0, 6))
+            dyn = [[[float(v) for v in np.r_[rng.uniform(-6, 6, 2), rng.uniform(0.2, 1.0, 2), 0.0, 1.0]]
+                    for _t in range(21)] for _o in range(n_obs)]
+            fake = sys.modules["navi_fast"]
+            n_before = len(fake.CALLS)
+            with contextlib.redirect_stdout(io.StringIO()):
+                actions, pred, cost, closest, refs = mi.run_step("work", dyn if n_obs else None, True)
+            assert len(fake.CALLS) == n_before + 1
+            tr = mi.traj_tracker
+            cases.append(dict(state=state.tolist(), map_polygons=[[list(v) for v in p_] for p_ in polys],
+                              dyn=dyn, goal=list(goal), params=fake.CALLS[-1],
+                              closest=[[list(v) for v in p_] for p_ in closest],
+                              ref_states=np.asarray(refs).tolist(), tuning=[float(v) for v in tr.tuning_params],
+                              stc_weights=[float(v) for v in tr.stc_weights],
+                              dyn_weights=[float(v) for v in tr.dyn_weights]))
+    finally:
+        os.chdir(cwd)
+    return cases
