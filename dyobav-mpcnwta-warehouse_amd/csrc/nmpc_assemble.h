@@ -8,7 +8,7 @@
 //   pkg_mpc_tracker/trajectory_tracker.py:291-317  list concatenation into the flat parameter vector
 //
 // Two kernels: select_static_kernel (one wavefront per instance; compute-light, latency-bound) writes the o_s block,
-// fill_kernel (grid-stride, 16-byte stores) writes everything else -- a pure HBM byte mover:
+// fill_kernel (one dword per lane, 256 B per wave-instruction) writes everything else -- a pure HBM byte mover:
 // algorithmic bytes per instance = 2 * sizeof(T) * np (every element written once, read or generated once).
 #pragma once
 
@@ -121,64 +121,51 @@ __global__ __launch_bounds__(64) void select_static_kernel(AsmParams<T> a)
 }
 
 template <typename T>
-__device__ __forceinline__ T asm_element(const AsmParams<T>& a, int b, int e, bool& skip)
+__device__ __forceinline__ T asm_element(const AsmParams<T>& a, unsigned b, unsigned e, bool& skip)
 {
     skip = false;
-    if (e < 2) return a.last_u[2 * b + e];
-    if (e < 5) return a.state[3 * b + (e - 2)];
-    if (e < 8) return a.ref_states[((size_t)b * a.N + (a.N - 1)) * 3 + (e - 5)]; // goal = last reference row
-    if (e < a.off_rs) return a.tuning[e - 8];
-    if (e < a.off_rv) return a.ref_states[(size_t)b * a.N * 3 + (e - a.off_rs)];
-    if (e < a.off_c0) return a.speed_ref[b];
-    if (e < a.off_os) return a.other_robots ? a.other_robots[(size_t)b * (a.off_os - a.off_c0) + (e - a.off_c0)] : T(0);
-    if (e < a.off_od) {
+    // largest blocks first: o_d (68 % of the vector at the yaml dimensions), then c_0/c (23 %)
+    if (e >= (unsigned)a.off_od && e < (unsigned)a.off_qstc) {
+        const unsigned i = e - a.off_od, per = 6 * (a.N + 1);
+        return (a.dyn && i < a.n_dyn * per) ? a.dyn[(size_t)b * (a.n_dyn * per) + i] : T(0);
+    }
+    if (e >= (unsigned)a.off_c0 && e < (unsigned)a.off_os)
+        return a.other_robots ? a.other_robots[(size_t)b * (a.off_os - a.off_c0) + (e - a.off_c0)] : T(0);
+    if (e >= (unsigned)a.off_os && e < (unsigned)a.off_od) {
         skip = true; // written by select_static_kernel
         return T(0);
     }
-    if (e < a.off_qstc) {
-        const int i = e - a.off_od, per = 6 * (a.N + 1);
-        return (a.dyn && i < a.n_dyn * per) ? a.dyn[(size_t)b * a.n_dyn * per + i] : T(0);
-    }
-    if (e < a.off_qdyn) return a.stc_weights[e - a.off_qstc];
-    return a.dyn_weights[e - a.off_qdyn];
+    if (e >= (unsigned)a.off_qdyn) return a.dyn_weights[e - a.off_qdyn];
+    if (e >= (unsigned)a.off_qstc) return a.stc_weights[e - a.off_qstc];
+    if (e >= (unsigned)a.off_rv) return a.speed_ref[b];
+    if (e >= (unsigned)a.off_rs) return a.ref_states[(size_t)b * a.N * 3 + (e - a.off_rs)];
+    if (e >= 8u) return a.tuning[e - 8];
+    if (e >= 5u) return a.ref_states[((size_t)b * a.N + (a.N - 1)) * 3 + (e - 5)]; // goal = last reference row
+    if (e >= 2u) return a.state[3 * b + (e - 2)];
+    return a.last_u[2 * b + e];
 }
 
-// Grid-stride byte mover over the flat B*np output; 4 consecutive elements per thread, one 16-byte (f32) / two
-// 16-byte (f64) stores when none of them belongs to the o_s block.
+// Byte mover: block = (instance, 1024-element chunk of its row) flattened into blockIdx.x; consecutive lanes handle
+// consecutive elements (256 B per wave-instruction on both the load and the store side; the only index division is
+// one scalar division per block), 4 independent loads in flight per lane.
 template <typename T>
-__global__ __launch_bounds__(256) void fill_kernel(AsmParams<T> a)
+__global__ __launch_bounds__(256) void fill_kernel(AsmParams<T> a, unsigned nchunk)
 {
-    const size_t total = (size_t)a.B * a.np;
-    const size_t nquad = (total + 3) / 4;
-    for (size_t qd = (size_t)blockIdx.x * blockDim.x + threadIdx.x; qd < nquad; qd += (size_t)gridDim.x * blockDim.x) {
-        const size_t f0 = qd * 4;
-        T v[4];
-        bool skip[4], any_skip = false;
-        int b = (int)(f0 / a.np), e = (int)(f0 - (size_t)b * a.np);
+    const unsigned b = blockIdx.x / nchunk, chunk = blockIdx.x - b * nchunk, np = (unsigned)a.np;
+    T* row = a.P + (size_t)b * np;
+    T v[4];
+    bool skip[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (f0 + i < total) {
-                v[i] = asm_element(a, b, e, skip[i]);
-            } else {
-                v[i] = 0;
-                skip[i] = true;
-            }
-            any_skip = any_skip || skip[i];
-            if (++e == a.np) {
-                e = 0;
-                ++b;
-            }
-        }
-        if (!any_skip) {
-            struct alignas(sizeof(T) * 4) V4 {
-                T x, y, z, w;
-            };
-            *reinterpret_cast<V4*>(a.P + f0) = V4{v[0], v[1], v[2], v[3]};
-        } else {
+    for (int j = 0; j < 4; ++j) {
+        const unsigned e = (chunk * 4u + j) * 256u + threadIdx.x;
+        skip[j] = true;
+        v[j] = 0;
+        if (e < np) v[j] = asm_element(a, b, e, skip[j]);
+    }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (!skip[i]) a.P[f0 + i] = v[i];
-        }
+    for (int j = 0; j < 4; ++j) {
+        const unsigned e = (chunk * 4u + j) * 256u + threadIdx.x;
+        if (!skip[j]) row[e] = v[j];
     }
 }
 

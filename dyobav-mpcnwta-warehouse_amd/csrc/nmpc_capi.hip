@@ -480,9 +480,10 @@ int assemble_params(nmpc_handle_s* h, const nmpc_assemble_args* g, int32_t B, T*
     if (lds > kLdsLimit) return fail(NMPC_ERR_UNSUPPORTED, "%d map polygons do not fit the selection kernel's LDS", a.M);
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(nmpc::select_static_kernel<T>, dim3(B), dim3(64), lds, h->stream, a);
-    const size_t nquad = ((size_t)B * a.np + 3) / 4;
-    const int blocks = (int)std::min<size_t>((nquad + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL(nmpc::fill_kernel<T>, dim3(blocks), dim3(256), 0, h->stream, a);
+    const unsigned nchunk = (unsigned)(a.np + 1023) / 1024u;
+    if ((unsigned long long)B * nchunk >= (1ull << 31))
+        return fail(NMPC_ERR_UNSUPPORTED, "B = %d too large for one assembly call; split the batch", B);
+    hipLaunchKernelGGL(nmpc::fill_kernel<T>, dim3((unsigned)B * nchunk), dim3(256), 0, h->stream, a, nchunk);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true;

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import dyobav_mpcnwta_warehouse_amd as nm
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65535
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dt, tdt = np.float32, torch.float32
 cfg = nm.default_config_struct()
