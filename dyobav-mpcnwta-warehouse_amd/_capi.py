@@ -57,6 +57,7 @@ EXPORTED_SYMBOLS = (
     "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_param_len", "nmpc_set_stream",
     "nmpc_solve_batch_f32", "nmpc_solve_batch_f64", "nmpc_eval_batch_f32", "nmpc_eval_batch_f64",
     "nmpc_assemble_params_f32", "nmpc_assemble_params_f64",
+    "nmpc_hypotheses_to_ellipses_f32", "nmpc_hypotheses_to_ellipses_f64",
     "nmpc_last_kernel_ms", "nmpc_kernel_info", "nmpc_selftest", "nmpc_last_error",
 )
 
@@ -97,6 +98,8 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
         getattr(lib, "nmpc_solve_batch_" + sfx).argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32]
         getattr(lib, "nmpc_eval_batch_" + sfx).argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp]
         getattr(lib, "nmpc_assemble_params_" + sfx).argtypes = [vp, C.POINTER(NmpcAssembleArgs), i32, vp]
+        getattr(lib, "nmpc_hypotheses_to_ellipses_" + sfx).argtypes = [vp, vp, i32, vp, i32, C.c_double, C.c_double,
+                                                                       C.c_double, C.c_double, i32, vp, vp]
     lib.nmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.nmpc_kernel_info.argtypes = [vp] + [C.POINTER(i32)] * 5
     lib.nmpc_selftest.argtypes = [vp]
@@ -215,6 +218,16 @@ class Handle:
         a.n_dyn = 0 if dyn_obstacles is None else int(dyn_obstacles.shape[1])
         fn = getattr(self._lib, "nmpc_assemble_params_" + _suffix(dtype))
         _check(fn(self._h, C.byref(a), int(B), p(P_out)))
+
+    def hypotheses_to_ellipses(self, dtype, hypos, cur, dyn_out, n_obs_out=None, human_size=0.2, eps=1.0, enlarge=2.0,
+                               extra_margin=0.0):
+        """``nmpc_hypotheses_to_ellipses_*``: device tensors ``hypos[B,N,P,2]``, ``cur[B,H,2]`` ->
+        ``dyn_out[B,Ndynobs,N+1,6]`` (+ ``n_obs_out[B]`` int32)."""
+        B, P, H = int(hypos.shape[0]), int(hypos.shape[2]), int(cur.shape[1])
+        fn = getattr(self._lib, "nmpc_hypotheses_to_ellipses_" + _suffix(dtype))
+        p = _Arg.ptr
+        _check(fn(self._h, p(hypos), P, p(cur), H, float(human_size), float(eps), float(enlarge), float(extra_margin),
+                  B, p(dyn_out), p(n_obs_out)))
 
     def solve(self, P: np.ndarray, u0=None, y0=None, c0=None, dtype=None, want_info=True) -> dict:
         """Solve a batch held in host memory; returns numpy arrays."""

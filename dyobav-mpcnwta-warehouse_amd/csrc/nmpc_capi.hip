@@ -15,6 +15,7 @@
 #include "../../include/nmpc_hip.h"
 #include "nmpc_assemble.h"
 #include "nmpc_device.h"
+#include "nmpc_hypotheses.h"
 
 namespace {
 
@@ -491,6 +492,39 @@ int assemble_params(nmpc_handle_s* h, const nmpc_assemble_args* g, int32_t B, T*
 }
 
 template <typename T>
+int hypotheses_to_ellipses(nmpc_handle_s* h, const T* hypos, int32_t P, const T* cur, int32_t H, double human_size,
+                           double eps, double enlarge, double extra_margin, int32_t B, T* dyn, int32_t* n_obs)
+{
+    if (!h || !hypos || !cur || !dyn) return fail(NMPC_ERR_INVALID_ARGUMENT, "null argument");
+    if (B <= 0) return B == 0 ? 0 : fail(NMPC_ERR_INVALID_ARGUMENT, "B = %d < 0", B);
+    if (P < 1 || P > 64) return fail(NMPC_ERR_UNSUPPORTED, "P = %d hypothesis points per time offset outside [1, 64]", P);
+    if (H < 0 || H > h->cfg.Ndynobs) return fail(NMPC_ERR_INVALID_ARGUMENT, "H = %d outside [0, Ndynobs]", H);
+    if (!is_device_ptr(hypos) || !is_device_ptr(cur) || !is_device_ptr(dyn) || (n_obs && !is_device_ptr(n_obs)))
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_hypotheses_to_ellipses: every array must be a device pointer");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    nmpc::HypParams<T> a;
+    a.B = B;
+    a.N = h->cfg.N_hor;
+    a.P = P;
+    a.H = H;
+    a.Ndyn = h->cfg.Ndynobs;
+    a.eps = (T)eps;
+    a.human_size = (T)human_size;
+    a.enlarge = (T)enlarge;
+    a.extra_margin = (T)extra_margin;
+    a.hypos = hypos;
+    a.cur = cur;
+    a.dyn = dyn;
+    a.n_obs = n_obs;
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(nmpc::hypotheses_kernel<T>, dim3(B), dim3(64), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return 0;
+}
+
+template <typename T>
 int set_lds_limit(nmpc_handle_s* h)
 {
     const Layout& L = h->lay<T>();
@@ -674,6 +708,20 @@ int nmpc_assemble_params_f32(nmpc_handle h, const nmpc_assemble_args* args, int3
 int nmpc_assemble_params_f64(nmpc_handle h, const nmpc_assemble_args* args, int32_t B, double* P)
 {
     return assemble_params<double>(h, args, B, P);
+}
+
+int nmpc_hypotheses_to_ellipses_f32(nmpc_handle h, const float* hypos, int32_t P, const float* cur, int32_t H,
+                                    double human_size, double eps, double enlarge, double extra_margin, int32_t B,
+                                    float* dyn, int32_t* n_obs)
+{
+    return hypotheses_to_ellipses<float>(h, hypos, P, cur, H, human_size, eps, enlarge, extra_margin, B, dyn, n_obs);
+}
+
+int nmpc_hypotheses_to_ellipses_f64(nmpc_handle h, const double* hypos, int32_t P, const double* cur, int32_t H,
+                                    double human_size, double eps, double enlarge, double extra_margin, int32_t B,
+                                    double* dyn, int32_t* n_obs)
+{
+    return hypotheses_to_ellipses<double>(h, hypos, P, cur, H, human_size, eps, enlarge, extra_margin, B, dyn, n_obs);
 }
 
 int nmpc_last_kernel_ms(nmpc_handle h, float* ms)

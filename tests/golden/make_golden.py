@@ -18,6 +18,8 @@ Fixtures written:
                        (pkg_mpc_tracker/trajectory_tracker.py:273-383) driven by a scripted fake solver.
   assemble_cases.json  inputs and the resulting parameter vector of MpcInterface.run_step
                        (interfaces/mpc_interface.py:52-100: closest-N polygons -> half-spaces, obstacle flattening).
+  hypotheses_cases.json hypothesis sets and the obstacle list produced by utils_test.fit_DBSCAN /
+                       fit_cluster2gaussian (utils_test.py:133-151) + main_base.py:293-302.
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -351,6 +353,11 @@ def main():
         json.dump(ac, fh)
     print("assemble_cases.json:", len(ac), "cases")
 
+    hc = hypotheses_fixture()
+    with open(os.path.join(HERE, "hypotheses_cases.json"), "w") as fh:
+        json.dump(hc, fh)
+    print("hypotheses_cases.json:", len(hc), "cases, n_obs =", [c["n_obs"] for c in hc])
+
 
 if __name__ == "__main__":
     main()
@@ -418,4 +425,46 @@ def assemble_fixture(K=6, seed=77):
                               dyn_weights=[float(v) for v in tr.dyn_weights]))
     finally:
         os.chdir(cwd)
+    return cases
+
+
+# ---------------------------------------------------------------------------------------------------------
+def hypotheses_fixture(K=8, seed=123):
+    """f2 ("next" row): multi-hypothesis predictions -> obstacle ellipses. Runs the reference's own
+    ``utils_test.fit_DBSCAN`` / ``fit_cluster2gaussian`` (src/utils_test.py:133-151, as called from
+    main_base.py:196-208 with eps=1, min_sample=2, enlarge=2, extra_margin=0) on random hypothesis sets and records the
+    list the simulator hands to the MPC interface (main_base.py:293-302: one [mu_x, mu_y, std_x, std_y, 0, 1] row per
+    cluster and time offset, current positions with HUMAN_SIZE at offset 0, [0,0,0,0,0,1] where a slot has no cluster)."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        import utils_test
+    rng = np.random.default_rng(seed)
+    HUMAN_SIZE, N = 0.2, 20
+    cases = []
+    for _ in range(K):
+        H = int(rng.integers(1, 4))
+        nh = int(rng.choice([5, 10, 20]))
+        cur = rng.uniform(-5, 5, (H, 2))
+        vel = rng.uniform(-1.2, 1.2, (H, 2))
+        hyp = np.zeros((N, H * nh, 2))
+        for t in range(N):
+            for h in range(H):
+                modes = int(rng.integers(1, 4))
+                centres = cur[h] + vel[h] * 0.2 * (t + 1) + rng.normal(0, 0.8 + 0.05 * t, (modes, 2))
+                which = rng.integers(0, modes, nh)
+                hyp[t, h * nh:(h + 1) * nh] = centres[which] + rng.normal(0, 0.12 + 0.01 * t, (nh, 2))
+        mu_list_list = [[c.tolist() for c in cur]]
+        std_list_list = [[[HUMAN_SIZE, HUMAN_SIZE] for _ in range(H)]]
+        for t in range(N):
+            clusters = utils_test.fit_DBSCAN(hyp[t], eps=1, min_sample=2)
+            mu_list, std_list = utils_test.fit_cluster2gaussian(clusters, enlarge=2, extra_margin=0)
+            mu_list_list.append([m.tolist() for m in mu_list])
+            std_list_list.append([s.tolist() for s in std_list])
+        # main_base.py:293-302
+        n_obs = max(len(m) for m in mu_list_list)
+        dyn_obs_list = [[[0, 0, 0, 0, 0, 1]] * (N + 1) for _ in range(n_obs)]
+        for Tt, (mu_list, std_list) in enumerate(zip(mu_list_list, std_list_list)):
+            for Nn, (mu, std) in enumerate(zip(mu_list, std_list)):
+                dyn_obs_list[Nn][Tt] = [mu[0], mu[1], std[0], std[1], 0, 1]
+        cases.append(dict(cur=cur.tolist(), hypos=hyp.tolist(), n_obs=n_obs, dyn_obs_list=dyn_obs_list,
+                          counts=[len(m) for m in mu_list_list]))
     return cases
