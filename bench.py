@@ -36,6 +36,8 @@ WORKLOADS = {
              "cfg1_b1024_n20_2x5"),
     "cfg2": ("batch=65536 main_eva.py scenarios, mpc_fast.yaml N=20, 4 obs x 10 hypotheses, 1 MI355X",
              "cfg2_b65536_n20_4x10"),
+    "cfg4": ("long horizon N=40, 8 obs x 20 hypotheses, batch=8192, 1 MI355X (obstacle table streamed from HBM)",
+             "cfg4_b8192_n40_8x20"),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
@@ -171,7 +173,7 @@ def main():
         flops_launch = float(np.sum((n_psi - n_grad) * ff + n_grad * 3 * ff))
         achieved_tf = flops_launch / (k_ms * 1e-3) / 1e12
         out = {
-            "metric": "MPC solves/sec (N=20, batched)",
+            "metric": f"MPC solves/sec (N={layout.N}, batched)",
             "value": value,
             "unit": "solves/s",
             "n_gpus": world,
@@ -190,7 +192,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": measured_traffic(args.workload, args.dtype, B),
-                         "kernel": "solve_kernel<float,3>" if args.dtype == "f32" else "solve_kernel<double,3>",
+                         "kernel": f"solve_kernel<{'float' if args.dtype == 'f32' else 'double'}, LPS={h.kernel_info()['lanes_per_step']}>",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_per_solve * B,
                          "valu": {"achieved": achieved_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": achieved_tf / VALU_PEAK_TFLOPS,

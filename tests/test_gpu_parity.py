@@ -319,3 +319,26 @@ def test_other_robots_nonzero_paths():
     fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "problem_n20.npz"))
     L = nm.scenarios.ParamLayout()
     assert (fx["P"][:, L.c0:L.c0 + 30] != 0).any() and (fx["P"][:, L.c:L.c + 600] != 0).any()
+
+
+def test_config2_full_batch_size_independent_properties():
+    """BASELINE configs[2] at FULL size (B = 65536, Ndynobs = 40, fp32): determinism across launches, permutation
+    equivariance on a slice, reported cost = f(u*) from the device evaluator, feasibility of every control."""
+    lay = nm.scenarios.ParamLayout(20, 10, 10, 40)
+    B = 65536
+    P = nm.scenarios.make_batch(B, lay, seed=1, n_ped=4, n_hyp=10).astype(np.float32)
+    pr = oracle.Problem(20, 10, 10, 40)
+    with nm.Handle(config_for(pr)) as h:
+        r1 = h.solve(P)
+        r2 = h.solve(P)
+        assert np.array_equal(r1["U"], r2["U"]) and np.array_equal(r1["iters"], r2["iters"])
+        idx = np.random.default_rng(3).permutation(B)[:4096]
+        r3 = h.solve(np.ascontiguousarray(P[idx]))
+        assert np.array_equal(r3["U"], r1["U"][idx]) and np.array_equal(r3["status"], r1["status"][idx])
+        ev = h.eval(P[:8192], r1["U"][:8192], np.zeros((8192, 40), np.float32), np.zeros(8192, np.float32), grad=False)
+        np.testing.assert_allclose(ev["psi"], r1["cost"][:8192], rtol=1e-6)
+    U = r1["U"]
+    assert np.isfinite(U).all() and set(np.unique(r1["status"])) <= {0, 1}
+    assert (U[:, 0::2] >= pr.lin_vel_min).all() and (U[:, 0::2] <= pr.lin_vel_max).all()
+    assert (np.abs(U[:, 1::2]) <= pr.ang_vel_max).all()
+    assert ((r1["iters"][:, 0] >= 2) & (r1["iters"][:, 0] <= 10)).all()
