@@ -7,6 +7,8 @@ Host side (Python, mirrors the reference's interface for the solve path only):
 * :mod:`.solver`             -- ``solver().run(p, ...)`` object of the generated module (``trajectory_tracker.py:13-15,
                                 54-66, 362``) and the batched front end ``BatchSolver``
 * :mod:`.trajectory_tracker` -- ``TrajectoryTracker.run_step`` (``trajectory_tracker.py:18-416``)
+* :mod:`.mpc_interface`      -- ``MpcInterface.run_step`` (``interfaces/mpc_interface.py:20-102``), static-obstacle
+                                marshalling on the device
 * :mod:`.solver_build`       -- analogue of ``src/solver_build.py``: compiles the HIP library and writes the
                                 ``mpc_solver/<optimizer_name>/`` module the reference imports
 * :mod:`.scenarios`          -- synthetic parameter batches of BASELINE.json's configurations

@@ -49,7 +49,7 @@ class NmpcAssembleArgs(C.Structure):
     _fields_ = [("last_u", C.c_void_p), ("state", C.c_void_p), ("ref_states", C.c_void_p), ("speed_ref", C.c_void_p),
                 ("tuning", C.c_void_p), ("other_robots", C.c_void_p), ("map_polygons", C.c_void_p),
                 ("n_map_polygons", C.c_int32), ("n_dyn", C.c_int32), ("dyn_obstacles", C.c_void_p),
-                ("stc_weights", C.c_void_p), ("dyn_weights", C.c_void_p)]
+                ("stc_weights", C.c_void_p), ("dyn_weights", C.c_void_p), ("selected", C.c_void_p)]
 
 
 # every symbol include/nmpc_hip.h declares (checked by the CPU test-suite against the built library)
@@ -204,7 +204,7 @@ class Handle:
                   p(c0), p(info), int(bool(sync))))
 
     def assemble_params(self, dtype, B, P_out, last_u, state, ref_states, speed_ref, tuning, stc_weights, dyn_weights,
-                        map_polygons=None, dyn_obstacles=None, other_robots=None):
+                        map_polygons=None, dyn_obstacles=None, other_robots=None, selected=None):
         """``nmpc_assemble_params_*``: device tensors in (torch / raw pointers), ``P_out[B, np]`` written on the
         handle's stream. ``map_polygons`` [M,4,2]; ``dyn_obstacles`` [B,n_dyn,N+1,6]."""
         a = NmpcAssembleArgs()
@@ -216,6 +216,7 @@ class Handle:
         a.n_map_polygons = 0 if map_polygons is None else int(map_polygons.shape[0])
         a.dyn_obstacles = p(dyn_obstacles)
         a.n_dyn = 0 if dyn_obstacles is None else int(dyn_obstacles.shape[1])
+        a.selected = p(selected)
         fn = getattr(self._lib, "nmpc_assemble_params_" + _suffix(dtype))
         _check(fn(self._h, C.byref(a), int(B), p(P_out)))
 

@@ -32,6 +32,7 @@ struct AsmParams {
     const T* stc_weights;  // [N]
     const T* dyn_weights;  // [N]
     T* P;                  // [B][np]
+    int* selected;         // [B][Nstc] indices of the chosen map polygons, nearest first, -1 = none (may be null)
 };
 
 __device__ __forceinline__ float thypot(float a, float b) { return hypotf(a, b); }
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(64) void select_static_kernel(AsmParams<T> a)
         if (lane == 0) {
             sel[s] = bv < BIG ? bi : -1;
             if (bv < BIG) dist[bi] = BIG;
+            if (a.selected) a.selected[(size_t)b * a.Nstc + s] = sel[s];
         }
         __syncthreads();
     }

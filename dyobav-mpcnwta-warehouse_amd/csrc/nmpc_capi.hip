@@ -477,6 +477,9 @@ int assemble_params(nmpc_handle_s* h, const nmpc_assemble_args* g, int32_t B, T*
     a.stc_weights = static_cast<const T*>(g->stc_weights);
     a.dyn_weights = static_cast<const T*>(g->dyn_weights);
     a.P = P;
+    a.selected = g->selected;
+    if (g->selected && !is_device_ptr(g->selected))
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_assemble_params: every array must be a device pointer");
     const size_t lds = (size_t)a.M * sizeof(T) + (size_t)a.Nstc * sizeof(int) + 16;
     if (lds > kLdsLimit) return fail(NMPC_ERR_UNSUPPORTED, "%d map polygons do not fit the selection kernel's LDS", a.M);
     HIP_TRY(hipEventRecord(h->ev0, h->stream));

@@ -85,3 +85,69 @@ def test_generated_module_is_importable_by_the_reference_convention(tmp_path):
     finally:
         sys.path.remove(os.path.dirname(mod))
         sys.modules.pop("navi_fast", None)
+
+
+def test_mpc_interface_matches_reference_recording(golden_dir):
+    """L3 adapter: MpcInterface.run_step with the static-obstacle marshalling on the device, against the recording of
+    the reference's MpcInterface.run_step (parameter vector handed to the solver + closest_obstacle_list)."""
+    import json
+    from dyobav_mpcnwta_warehouse_amd.mpc_interface import MpcInterface
+    from oracle import assemble as oa
+
+    class Fake:
+        def __init__(self):
+            self.calls = []
+
+        def run(self, p, *a, **k):
+            self.calls.append([float(v) for v in p])
+            return types.SimpleNamespace(solution=[0.3, 0.05] * 20, cost=1.0, exit_status="Converged", solve_time_ms=1.0)
+
+    for c in json.load(open(os.path.join(golden_dir, "assemble_cases.json"))):
+        fake = Fake()
+        geo = types.SimpleNamespace(processed_obstacle_list=[[tuple(v) for v in q] for q in c["map_polygons"]])
+        mi = MpcInterface("mpc_fast.yaml", np.array(c["state"]), geo, verbose=False, solver_factory=lambda: fake)
+        mi.update_global_path([tuple(c["goal"])])
+        actions, pred, cost, closest, refs = mi.run_step("work", c["dyn"] if len(c["dyn"]) else None, True)
+        p, p_ref = np.array(fake.calls[-1]), np.array(c["params"])
+        np.testing.assert_allclose(p[:728], p_ref[:728], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(p[848:], p_ref[848:], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(np.array(oa.canonical_static_block(p[728:848])),
+                                   np.array(oa.canonical_static_block(p_ref[728:848])), rtol=0, atol=1e-7)
+        key = lambda polys: sorted(tuple(map(tuple, np.round(np.array(q), 9))) for q in polys)
+        assert key(closest) == key(c["closest"])
+        np.testing.assert_allclose(np.asarray(refs), np.array(c["ref_states"]), atol=1e-12)
+        assert len(actions) == 1 and len(pred) == 20 and cost == 1.0
+
+
+def test_config0_like_closed_loop_one_robot_two_pedestrians():
+    """BASELINE configs[0] (functional case): warehouse-like loop, 1 robot, 2 pedestrians on constant-velocity
+    predictions, static boxes, mpc_default.yaml, GPU solver behind MpcInterface/TrajectoryTracker. The robot makes
+    progress along the path, never enters a static box or a pedestrian disc, and every solve returns a legal status."""
+    from dyobav_mpcnwta_warehouse_amd.mpc_interface import MpcInterface
+    boxes = [[(3.0, 1.2), (2.0, 1.2), (2.0, 0.6), (3.0, 0.6)], [(5.5, -0.6), (4.5, -0.6), (4.5, -1.4), (5.5, -1.4)],
+             [(8.0, 1.5), (7.0, 1.5), (7.0, 0.7), (8.0, 0.7)]] + \
+            [[(20.0 + i, 20.0), (19.5 + i, 20.0), (19.5 + i, 19.5), (20.0 + i, 19.5)] for i in range(9)]
+    geo = types.SimpleNamespace(processed_obstacle_list=boxes)
+    mi = MpcInterface("mpc_default.yaml", np.array([0.0, 0.0, 0.0]), geo, verbose=False)
+    mi.update_global_path([(10.0, 0.0)])
+    peds = np.array([[6.0, 2.5], [9.0, -2.0]])
+    pvel = np.array([[-0.6, -0.5], [-0.8, 0.35]])
+    state = np.array([0.0, 0.0, 0.0])
+    traj, stats = [state.copy()], []
+    for step in range(40):
+        dyn = [[[float(p[0] + v[0] * 0.2 * t), float(p[1] + v[1] * 0.2 * t), 0.2 + 0.03 * t, 0.2 + 0.03 * t, 0, 1]
+                for t in range(21)] for p, v in zip(peds, pvel)]
+        mi.set_current_state(state)
+        actions, pred, cost, closest, refs = mi.run_step("work", dyn, True)
+        assert len(closest) == 10 and np.isfinite(cost)
+        state = mi.state.copy()
+        peds = peds + pvel * 0.2
+        traj.append(state.copy())
+        for p in peds:
+            assert np.hypot(*(state[:2] - p)) > 0.2          # main_pre.check_collision: HUMAN_SIZE
+        for q in boxes[:3]:
+            xs, ys = [v[0] for v in q], [v[1] for v in q]
+            assert not (min(xs) < state[0] < max(xs) and min(ys) < state[1] < max(ys))
+    traj = np.array(traj)
+    assert traj[-1, 0] > 5.0 and np.abs(traj[:, 1]).max() < 2.5
+    assert len(mi.traj_tracker.past_actions) == 40
