@@ -764,15 +764,18 @@ int nmpc_selftest(nmpc_handle h)
 {
     if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    int* d = nullptr;
-    HIP_TRY(hipMalloc(&d, 2 * sizeof(int)));
-    HIP_TRY(hipMemsetAsync(d, 0, 2 * sizeof(int), h->stream));
-    hipLaunchKernelGGL(selftest_kernel<float>, dim3(1), dim3(64), 0, h->stream, d);
-    hipLaunchKernelGGL(selftest_kernel<double>, dim3(1), dim3(64), 0, h->stream, d + 1);
+    DevBuf buf; // freed on every path below
+    if (int rc = buf.reserve(2 * sizeof(int))) return rc;
+    int* d = static_cast<int*>(buf.p);
     int res[2] = {-1, -1};
-    hipError_t e = hipMemcpyAsync(res, d, sizeof res, hipMemcpyDeviceToHost, h->stream);
+    hipError_t e = hipMemsetAsync(d, 0, 2 * sizeof(int), h->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(selftest_kernel<float>, dim3(1), dim3(64), 0, h->stream, d);
+        hipLaunchKernelGGL(selftest_kernel<double>, dim3(1), dim3(64), 0, h->stream, d + 1);
+        e = hipMemcpyAsync(res, d, sizeof res, hipMemcpyDeviceToHost, h->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d);
+    buf.release();
     if (e != hipSuccess) return fail(NMPC_ERR_HIP, "selftest: %s", hipGetErrorString(e));
     if (res[0] || res[1]) {
         g_err = "wave primitive self-test failed: f32 mask " + std::to_string(res[0]) + ", f64 mask " +

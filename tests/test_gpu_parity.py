@@ -342,3 +342,22 @@ def test_config2_full_batch_size_independent_properties():
     assert (U[:, 0::2] >= pr.lin_vel_min).all() and (U[:, 0::2] <= pr.lin_vel_max).all()
     assert (np.abs(U[:, 1::2]) <= pr.ang_vel_max).all()
     assert ((r1["iters"][:, 0] >= 2) & (r1["iters"][:, 0] <= 10)).all()
+
+
+def test_non_finite_inputs_and_optional_outputs(handle20):
+    """NaN in the parameters -> NMPC_NOT_FINITE (OpEn: SolverError::NotFiniteComputation, run() returns None); every
+    optional output of the C ABI may be NULL; B = 0 is a no-op."""
+    L = nm.scenarios.ParamLayout()
+    P = nm.scenarios.make_batch(8, L, seed=50, n_ped=0, n_boxes=0)
+    P[3, L.s0] = np.nan
+    r = handle20.solve(P)
+    assert r["status"][3] == 3 and (np.delete(r["status"], 3) <= 1).all()
+    U = np.empty((8, 40))
+    handle20.solve_raw(np.float64, P, 8, U)                      # cost/status/iters/u0/y/c0/info all NULL
+    assert np.array_equal(np.delete(U, 3, axis=0), np.delete(r["U"], 3, axis=0))
+    handle20.solve_raw(np.float64, P, 0, U)
+    from dyobav_mpcnwta_warehouse_amd.solver import Solver
+    s = Solver(config_for(oracle.Problem()))
+    assert s.run(P[3].tolist()) is None
+    assert s.run(P[0].tolist()) is not None
+    s.close()

@@ -1,4 +1,8 @@
 #!/usr/bin/env python3
+"""Iterate-path parity probe (GPU fp64 vs CPU oracle) for two scenario families, two Lipschitz-estimator steps and
+growing iteration caps: the measurement behind DESIGN.md's "parity protocol" (with OpEn's step 1e-12 the first step
+length already differs by ~1e-3 between evaluation orders; with 1e-6 / 1e-4 the paths agree to 1e-9 / 1e-12).
+Writes gpurun_out/path_probe2.txt."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
