@@ -96,7 +96,8 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+        dist.init_process_group("nccl", rank=rank, world_size=world,           # "nccl" is RCCL on ROCm
+                                device_id=torch.device("cuda", local_rank))
 
     desc, key = WORKLOADS[args.workload]
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
