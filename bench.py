@@ -76,6 +76,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout must carry exactly ONE JSON line: RCCL / HIP libraries print banners and warnings on fd 1, so keep a
+    # private copy of the real stdout for the result and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -205,7 +211,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity_sample"] = cpu_baseline(layout, P_host, U, status)
-        print(json.dumps(out), flush=True)
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
 
     h.close()
     if use_dist:
