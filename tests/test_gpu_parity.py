@@ -361,3 +361,28 @@ def test_non_finite_inputs_and_optional_outputs(handle20):
     assert s.run(P[3].tolist()) is None
     assert s.run(P[0].tolist()) is not None
     s.close()
+
+
+@pytest.mark.parametrize("fixture", ["problem_n20", "problem_small"])
+def test_iterate_path_on_golden_inputs_all_terms_active(fixture, request):
+    """Solve (short, fixed iteration caps) the golden parameter vectors -- rotated ellipses, active fleet terms, robot
+    driven through polygons, every weight non-zero -- from their own u as initial guess: GPU fp64 vs oracle."""
+    fx, pr = request.getfixturevalue(fixture)
+    P, U0 = fx["P"], fx["U"]
+    for mo, mi in ((1, 3), (2, 12)):
+        op = oracle.Options(max_outer=mo, max_inner=mi, lip_delta=1e-4, lip_eps=1e-4)
+        cfg = config_for(pr, max_outer_iterations=mo, max_inner_iterations=mi, lip_delta_f64=1e-4, lip_eps_f64=1e-4)
+        with nm.Handle(cfg) as h:
+            r = h.solve(P, u0=U0)
+        du = []
+        for b in range(P.shape[0]):
+            u, y, res = oracle.solve(pr, op, P[b], u0=U0[b])
+            assert r["iters"][b, 1] == res["inner_iters"], (b, mo, mi)
+            du.append(np.abs(r["U"][b] - u).max())
+            assert r["cost"][b] == pytest.approx(res["cost"], rel=1e-3)
+        du = np.array(du)
+        # these inputs are extreme (robot inside obstacles, costs ~1e4-1e5): rounding noise is amplified on a few of
+        # them after a dozen iterations; the bulk follows the oracle's path to 1e-6
+        assert np.quantile(du, 0.8) < 1e-6 and du.max() < 5e-3, (mo, mi, np.sort(du)[-4:])
+        if mi <= 3:
+            assert du.max() < 1e-6
