@@ -54,7 +54,7 @@ class NmpcAssembleArgs(C.Structure):
 
 # every symbol include/nmpc_hip.h declares (checked by the CPU test-suite against the built library)
 EXPORTED_SYMBOLS = (
-    "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_param_len", "nmpc_set_stream",
+    "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_param_len", "nmpc_set_stream", "nmpc_use_own_stream",
     "nmpc_solve_batch_f32", "nmpc_solve_batch_f64", "nmpc_eval_batch_f32", "nmpc_eval_batch_f64",
     "nmpc_assemble_params_f32", "nmpc_assemble_params_f64",
     "nmpc_hypotheses_to_ellipses_f32", "nmpc_hypotheses_to_ellipses_f64",
@@ -94,6 +94,7 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     lib.nmpc_destroy.argtypes = [vp]
     lib.nmpc_param_len.argtypes = [vp]
     lib.nmpc_set_stream.argtypes = [vp, vp]
+    lib.nmpc_use_own_stream.argtypes = [vp]
     for sfx in ("f32", "f64"):
         getattr(lib, "nmpc_solve_batch_" + sfx).argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32]
         getattr(lib, "nmpc_eval_batch_" + sfx).argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp]
@@ -179,7 +180,12 @@ class Handle:
 
     # ------------------------------------------------------------------------------------------------
     def set_stream(self, stream_ptr: Optional[int]):
-        _check(self._lib.nmpc_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+        """``stream_ptr``: a ``hipStream_t`` as an int (0 = the null stream = torch's default stream); ``None`` = the
+        handle's own non-blocking stream."""
+        if stream_ptr is None:
+            _check(self._lib.nmpc_use_own_stream(self._h))
+        else:
+            _check(self._lib.nmpc_set_stream(self._h, C.c_void_p(int(stream_ptr))))
 
     def selftest(self) -> int:
         return _check(self._lib.nmpc_selftest(self._h))

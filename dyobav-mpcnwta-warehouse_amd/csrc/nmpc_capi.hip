@@ -673,7 +673,14 @@ int nmpc_param_len(nmpc_handle h)
 int nmpc_set_stream(nmpc_handle h, void* s)
 {
     if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
-    h->stream = s ? static_cast<hipStream_t>(s) : h->own_stream;
+    h->stream = static_cast<hipStream_t>(s); // NULL is a stream too: the HIP null stream (torch's default stream)
+    return 0;
+}
+
+int nmpc_use_own_stream(nmpc_handle h)
+{
+    if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
+    h->stream = h->own_stream;
     return 0;
 }
 

@@ -1,0 +1,258 @@
+"""Batched closed-loop evaluator ("next" row f3): B independent warehouse scenarios advanced in lock-step on the device.
+
+Semantics of the reference's evaluation loop for the MPC tracker with the constant-velocity predictor
+(``/root/reference/src``):
+
+* ``MainBase.run_once`` / ``run_one_step``                      main_base.py:267-346, 348-425
+* ``MainBase.run_cv_prediction`` + ``CvmpInterface``            main_base.py:238-264, interfaces/cvmp_interface.py:24-57
+  (mean step of the last <= 5 positions, extrapolated; std 1.0 for predicted offsets, HUMAN_SIZE at offset 0)
+* obstacle rows ``[mu_x, mu_y, std_x, std_y, 0, 1]``            main_base.py:293-302
+* ``MpcInterface.run_step`` -> ``TrajectoryTracker.run_step``   interfaces/mpc_interface.py:52-71, trajectory_tracker.py:273-337
+  (reference-state window, speed-reference rule, previous action; multipliers carried between solves)
+* no-backward clip, robot / pedestrian motion                  main_base.py:320-324, basic_agent.py:52-82
+* metrics                                                       main_pre.py:20-53, main_base.py:326-335, 427-435
+
+One time step = CV prediction -> obstacle rows -> reference windows -> ``nmpc_assemble_params`` (f1) ->
+``nmpc_solve_batch`` -> first action -> agent motion -> metrics, for all scenarios at once; nothing leaves HBM
+between steps. Where the reference runs ``max_num_run`` scenarios one after another (main_base.py:448-464), this
+runs them side by side. Pedestrian stagger uses a seeded torch generator (the reference's ``random`` is unseeded).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _capi
+from .trajectory_tracker import TrajectoryTracker
+
+HUMAN_SIZE = 0.2   # main_base.py:75, main_pre.py:18
+HUMAN_VMAX = 1.5   # main_base.py:76
+
+
+@dataclass
+class EvaluationResult:
+    collision: np.ndarray        # [B] bool   (main_base.py:366-371; a time-out counts as a collision, :407-410)
+    complete: np.ndarray         # [B] bool
+    steps: np.ndarray            # [B] int    time steps executed
+    smoothness: np.ndarray       # [B, 2]     mean |2nd difference| of (v, w)        (main_pre.calc_action_smoothness)
+    clearance: np.ndarray        # [B]        min distance to the static polygons     (calc_minimal_obstacle_distance)
+    clearance_dyn: np.ndarray    # [B]        min distance to a pedestrian            (calc_minimal_dynamic_obstacle_distance)
+    deviation: np.ndarray        # [B, 2]     mean / max distance to the reference trajectory (calc_deviation_distance)
+    trajectory: np.ndarray       # [B, T+1, 3] robot states (rows after the end repeat the last state)
+    actions: np.ndarray          # [B, T, 2]  raw solver actions
+    solve_ms: List[float]        # kernel time of every batched solve
+
+
+class BatchEvaluator:
+    def __init__(self, config: _capi.NmpcConfigStruct, robot_starts: np.ndarray, robot_paths: Sequence[Sequence[tuple]],
+                 human_starts: np.ndarray, human_paths: np.ndarray, map_polygons: np.ndarray, dtype=np.float64,
+                 human_stagger: float = 0.0, seed: int = 0, mode: str = "work",
+                 tuning: Optional[Sequence[float]] = None, lin_vel_max: float = 1.5):
+        import torch
+        self.torch = torch
+        self.cfg = config
+        self.dt = np.dtype(dtype)
+        self.tdt = torch.float32 if self.dt == np.float32 else torch.float64
+        self.dev = torch.device("cuda", config.device_id)
+        self.h = _capi.Handle(config)
+        self.h.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        self.N, self.ts = config.N_hor, config.ts
+        B = self.B = robot_starts.shape[0]
+        T = lambda x, dt=None: torch.as_tensor(np.ascontiguousarray(x), dtype=dt or self.tdt, device=self.dev)
+        self.robot = T(robot_starts)                               # [B,3]
+        self.goal = T(np.array([p[-1] for p in robot_paths], dtype=float))   # [B,2]
+        self.humans = T(human_starts)                              # [B,H,2]
+        self.H = self.humans.shape[1]
+        self.hpath = T(human_paths)                                # [B,H,W,2]
+        self.hidx = torch.zeros(B, self.H, dtype=torch.long, device=self.dev)
+        self.hist = self.humans[:, :, None, :].repeat(1, 1, 5, 1)  # last <= 5 positions, newest last
+        self.hcount = torch.ones(B, self.H, dtype=torch.long, device=self.dev)
+        self.polys = T(map_polygons)                               # [M,4,2]
+        self.stagger = float(human_stagger)
+        self.gen = torch.Generator(device=self.dev).manual_seed(seed)
+        scale = {"safe": 0.2, "work": 0.8, "super": 1.0}[mode]
+        self.base_speed = lin_vel_max * scale
+        self.lin_vel_max = lin_vel_max
+        # global reference trajectories: TrajectoryTracker.get_ref_traj per scenario (host, once), padded
+        trajs = [np.array(TrajectoryTracker.get_ref_traj(self.ts, list(p), tuple(s), self.base_speed))
+                 for p, s in zip(robot_paths, robot_starts)]
+        self.ref_len = torch.as_tensor([len(t) for t in trajs], device=self.dev)
+        Lmax = max(len(t) for t in trajs)
+        pad = np.stack([np.concatenate([t, np.repeat(t[-1:], Lmax - len(t), axis=0)]) for t in trajs])
+        self.ref_traj = T(pad)                                     # [B,Lmax,3]
+        self.idx_ref = torch.zeros(B, dtype=torch.long, device=self.dev)
+        self.tuning = T(np.asarray(tuning if tuning is not None else
+                                   (0.0, 10.0, 0.0, 0.0, 0.0, 0.0, 0.0, 100.0, 10.0, 20.0), dtype=float))
+        self.stcw = torch.full((self.N,), 10.0, dtype=self.tdt, device=self.dev)   # set_obstacle_weights(10, 10)
+        self.dynw = torch.full((self.N,), 10.0, dtype=self.tdt, device=self.dev)
+        self.P = torch.empty(B, self.h.np_, dtype=self.tdt, device=self.dev)
+        self.U = torch.empty(B, 2 * self.N, dtype=self.tdt, device=self.dev)
+        self.y = torch.zeros(B, 2 * self.N, dtype=self.tdt, device=self.dev)
+        self.status = torch.empty(B, dtype=torch.int32, device=self.dev)
+
+    # ---------------------------------------------------------------------------------------------------------
+    def _predict_cv(self):
+        """[B,H,N+1,6] obstacle rows from the constant-velocity extrapolation of the last <= 5 positions."""
+        torch = self.torch
+        B, H, N = self.B, self.H, self.N
+        diffs = self.hist[:, :, 1:, :] - self.hist[:, :, :-1, :]                 # [B,H,4,2], newest last
+        nd = (self.hcount - 1).clamp(min=0, max=4)                               # usable differences
+        k = torch.arange(4, device=self.dev)[None, None, :]
+        mask = (k >= (4 - nd[..., None])).to(self.tdt)[..., None]
+        vel = (diffs * mask).sum(dim=2) / nd.clamp(min=1)[..., None].to(self.tdt)
+        off = torch.arange(0, N + 1, device=self.dev, dtype=self.tdt)[None, None, :, None]
+        rows = torch.zeros(B, H, N + 1, 6, dtype=self.tdt, device=self.dev)
+        rows[..., 0:2] = self.humans[:, :, None, :] + vel[:, :, None, :] * off
+        rows[..., 2:4] = 1.0
+        rows[:, :, 0, 2:4] = HUMAN_SIZE
+        rows[..., 5] = 1.0
+        return rows
+
+    def _ref_states(self):
+        """TrajectoryTracker.get_ref_states for all scenarios (note the reference passes N_hor as ``action_steps``,
+        trajectory_tracker.py:186-187, so the search window is [idx - N, idx + 5N); N rows are taken -- the
+        reference's default ``horizon=20`` equals N_hor in both shipped yaml files)."""
+        torch = self.torch
+        N, hor = self.N, self.N
+        Lmax = self.ref_traj.shape[1]
+        j = torch.arange(Lmax, device=self.dev)[None, :]
+        lo = (self.idx_ref - N).clamp(min=0)[:, None]
+        hi = torch.minimum(self.ref_len, self.idx_ref + 5 * N)[:, None]
+        d = torch.hypot(self.robot[:, None, 0] - self.ref_traj[:, :, 0], self.robot[:, None, 1] - self.ref_traj[:, :, 1])
+        d = torch.where((j >= lo) & (j < hi), d, torch.full_like(d, float("inf")))
+        self.idx_ref = torch.argmin(d, dim=1)               # first minimum, like list.index(min(...))
+        rows = self.idx_ref[:, None] + torch.arange(hor, device=self.dev)[None, :]
+        rows = torch.minimum(rows, (self.ref_len - 1)[:, None])
+        return torch.gather(self.ref_traj, 1, rows[..., None].expand(-1, -1, 3)).contiguous()[:, :N]
+
+    def _in_polygon(self, pts):
+        """[B] strictly inside any convex quadrilateral (shapely Polygon.contains)."""
+        a = self.polys[None]                                                     # [1,M,4,2]
+        b = self.torch.roll(self.polys, -1, dims=1)[None]
+        p = pts[:, None, None, :]
+        cross = (b[..., 0] - a[..., 0]) * (p[..., 1] - a[..., 1]) - (b[..., 1] - a[..., 1]) * (p[..., 0] - a[..., 0])
+        inside = (cross > 0).all(dim=2) | (cross < 0).all(dim=2)
+        return inside.any(dim=1)
+
+    def _polygon_distance(self, pts):
+        """[B] distance to the closest polygon (0 inside), shapely Polygon.distance(Point)."""
+        torch = self.torch
+        a = self.polys[None]
+        b = torch.roll(self.polys, -1, dims=1)[None]
+        p = pts[:, None, None, :]
+        ab = b - a
+        t = (((p - a) * ab).sum(-1) / (ab * ab).sum(-1)).clamp(0, 1)
+        d = torch.linalg.norm(a + t[..., None] * ab - p, dim=-1).min(dim=2).values     # [B,M]
+        cross = ab[..., 0] * (p[..., 1] - a[..., 1]) - ab[..., 1] * (p[..., 0] - a[..., 0])
+        inside = (cross > 0).all(dim=2) | (cross < 0).all(dim=2)
+        return torch.where(inside, torch.zeros_like(d), d).min(dim=1).values
+
+    def _step_humans(self):
+        torch = self.torch
+        W = self.hpath.shape[2]
+        tgt = torch.gather(self.hpath, 2, self.hidx.clamp(max=W - 1)[..., None, None].expand(-1, -1, 1, 2))[:, :, 0]
+        dist = torch.linalg.norm(tgt - self.humans, dim=-1)
+        adv = (dist < HUMAN_VMAX * self.ts) & (self.hidx < W)                    # basic_agent.py:57-59
+        self.hidx = self.hidx + adv.long()
+        moving = self.hidx < W
+        tgt = torch.gather(self.hpath, 2, self.hidx.clamp(max=W - 1)[..., None, None].expand(-1, -1, 1, 2))[:, :, 0]
+        dist = torch.linalg.norm(tgt - self.humans, dim=-1).clamp(min=1e-12)
+        dire = (tgt - self.humans) / dist[..., None]
+        if self.stagger > 0:
+            sign = torch.randint(0, 2, dist.shape, generator=self.gen, device=self.dev) * 2 - 1
+            mag = torch.randint(0, 11, dist.shape, generator=self.gen, device=self.dev).to(self.tdt) / 10
+            st = (sign.to(self.tdt) * mag * self.stagger)[..., None]
+        else:
+            st = 0.0
+        new = self.humans + self.ts * (dire * HUMAN_VMAX + st)                   # omnidirectional model
+        self.humans = torch.where(moving[..., None], new, self.humans)
+        # past_traj grows only while the pedestrian moves (basic_agent.py:72-82)
+        shifted = torch.cat([self.hist[:, :, 1:], self.humans[:, :, None, :]], dim=2)
+        self.hist = torch.where(moving[..., None, None], shifted, self.hist)
+        self.hcount = self.hcount + moving.long()
+
+    # ---------------------------------------------------------------------------------------------------------
+    def run(self, max_steps: int = 120, record: Optional[list] = None) -> EvaluationResult:
+        """``record``: if a list, one dict per time step is appended with host copies of what the step saw and
+        produced (robot, humans, P, y_in, U) -- for step-by-step checks against the sequential API; costs a
+        device->host copy per step."""
+        torch = self.torch
+        B, N, ts = self.B, self.N, self.ts
+        alive = torch.ones(B, dtype=torch.bool, device=self.dev)
+        collision = torch.zeros(B, dtype=torch.bool, device=self.dev)
+        complete = torch.zeros(B, dtype=torch.bool, device=self.dev)
+        steps = torch.zeros(B, dtype=torch.long, device=self.dev)
+        last_u = torch.zeros(B, 2, dtype=self.tdt, device=self.dev)
+        traj = [self.robot.clone()]
+        acts, solve_ms = [], []
+        clr_dyn = torch.full((B,), float("inf"), dtype=self.tdt, device=self.dev)
+        clr_stc = self._polygon_distance(self.robot[:, :2])
+        d0 = torch.cdist(self.robot[:, None, :2], self.ref_traj[:, :, :2])[:, 0]
+        dev_sum = d0.min(dim=1).values.clone()      # trajectory metrics include the start state (robot.past_traj[0])
+        dev_max = dev_sum.clone()
+        n_traj = torch.ones(B, dtype=self.tdt, device=self.dev)
+        for kt in range(max_steps):
+            if not bool(alive.any()):
+                break
+            dyn = self._predict_cv()
+            refs = self._ref_states()
+            dist_goal = torch.hypot(self.robot[:, 0] - self.goal[:, 0], self.robot[:, 1] - self.goal[:, 1])
+            near = dist_goal < self.base_speed * N * ts
+            speed = torch.where(near, torch.clamp(dist_goal / N / ts, min=self.lin_vel_max),
+                                torch.full_like(dist_goal, self.base_speed))     # sic: max(), trajectory_tracker.py:308-309
+            self.h.assemble_params(self.dt, B, self.P, last_u.contiguous(), self.robot.contiguous(), refs, speed,
+                                   self.tuning, self.stcw, self.dynw, self.polys, dyn.contiguous())
+            if record is not None:
+                rec = dict(robot=self.robot.cpu().numpy(), humans=self.humans.cpu().numpy(), alive=alive.cpu().numpy(),
+                           y_in=self.y.cpu().numpy())
+            self.h.solve_raw(self.dt, self.P, B, self.U, status=self.status, y=self.y, y_is_input=kt > 0, sync=False)
+            if record is not None:
+                rec.update(P=self.P.cpu().numpy(), U=self.U.cpu().numpy())
+                record.append(rec)
+            solve_ms.append(self.h.last_kernel_ms())
+            raw = self.U[:, :2].clone()
+            act = torch.where((raw[:, 0:1] < 0), torch.zeros_like(raw), raw)     # no-backward, main_base.py:320-321
+            th, v, w = self.robot[:, 2], act[:, 0], act[:, 1]
+            hh = 0.5 * ts * w
+            cc = (torch.cos(th) + 4 * torch.cos(th + hh) + torch.cos(th + 2 * hh)) / 6
+            ss = (torch.sin(th) + 4 * torch.sin(th + hh) + torch.sin(th + 2 * hh)) / 6
+            new_robot = torch.stack([self.robot[:, 0] + ts * v * cc, self.robot[:, 1] + ts * v * ss, th + ts * w], dim=1)
+            self.robot = torch.where(alive[:, None], new_robot, self.robot)
+            last_u = torch.where(alive[:, None], raw, last_u)
+            self._step_humans()
+            steps = steps + alive.long()
+            traj.append(self.robot.clone())
+            acts.append(torch.where(alive[:, None], raw, torch.full_like(raw, float("nan"))))
+            # metrics and flags (main_base.py:326-335)
+            dd = torch.linalg.norm(self.robot[:, None, :2] - self.humans, dim=-1).min(dim=1).values
+            clr_dyn = torch.where(alive, torch.minimum(clr_dyn, dd), clr_dyn)
+            clr_stc = torch.where(alive, torch.minimum(clr_stc, self._polygon_distance(self.robot[:, :2])), clr_stc)
+            dref = torch.cdist(self.robot[:, None, :2], self.ref_traj[:, :, :2])[:, 0]
+            dref = torch.where(torch.arange(dref.shape[1], device=self.dev)[None] < self.ref_len[:, None], dref,
+                               torch.full_like(dref, float("inf"))).min(dim=1).values
+            dev_sum = dev_sum + torch.where(alive, dref, torch.zeros_like(dref))
+            dev_max = torch.where(alive, torch.maximum(dev_max, dref), dev_max)
+            n_traj = n_traj + alive.to(self.tdt)
+            col = alive & (self._in_polygon(self.robot[:, :2]) | (dd <= HUMAN_SIZE))
+            done = alive & ~col & ((self.robot[:, 0] - self.goal[:, 0]).abs() <= 0.5) & \
+                ((self.robot[:, 1] - self.goal[:, 1]).abs() <= 0.5) & (act[:, 0].abs() < 0.4)
+            collision |= col
+            complete |= done
+            alive = alive & ~col & ~done
+        collision |= alive                                                       # time-out, main_base.py:407-410
+        A = torch.stack(acts, dim=1) if acts else torch.zeros(B, 0, 2, dtype=self.tdt, device=self.dev)
+        smooth = torch.full((B, 2), float("nan"), dtype=self.tdt, device=self.dev)
+        if A.shape[1] >= 3:
+            d2 = (A[:, 2:] - 2 * A[:, 1:-1] + A[:, :-2]).abs()
+            valid = ~torch.isnan(d2[..., 0])
+            smooth = torch.nan_to_num(d2, nan=0.0).sum(dim=1) / valid.sum(dim=1).clamp(min=1)[:, None].to(self.tdt)
+        return EvaluationResult(
+            collision=collision.cpu().numpy(), complete=complete.cpu().numpy(), steps=steps.cpu().numpy(),
+            smoothness=smooth.cpu().numpy(), clearance=clr_stc.cpu().numpy(), clearance_dyn=clr_dyn.cpu().numpy(),
+            deviation=torch.stack([dev_sum / n_traj, dev_max], dim=1).cpu().numpy(),
+            trajectory=torch.stack(traj, dim=1).cpu().numpy(), actions=A.cpu().numpy(), solve_ms=solve_ms)
+
+    def close(self):
+        self.h.close()
