@@ -13,6 +13,8 @@ Host side (Python, mirrors the reference's interface for the solve path only):
                                 ``mpc_solver/<optimizer_name>/`` module the reference imports
 * :mod:`.evaluate`           -- ``BatchEvaluator``: the closed-loop evaluation of ``main_base.py:267-346, 448-464`` for B
                                 scenarios in lock-step on the device (row f3)
+* :mod:`.tcp`                -- OpEn's TCP/JSON wire format in front of the solver + the ``OptimizerTcpManager`` surface
+                                used by ``TrajectoryTracker(use_tcp=True)`` (row f4)
 * :mod:`.scenarios`          -- synthetic parameter batches of BASELINE.json's configurations
 * :mod:`.sharding`           -- one process per GPU, contiguous batch shards, RCCL gather of the results
 

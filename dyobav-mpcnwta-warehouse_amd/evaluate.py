@@ -49,7 +49,7 @@ class BatchEvaluator:
     def __init__(self, config: _capi.NmpcConfigStruct, robot_starts: np.ndarray, robot_paths: Sequence[Sequence[tuple]],
                  human_starts: np.ndarray, human_paths: np.ndarray, map_polygons: np.ndarray, dtype=np.float64,
                  human_stagger: float = 0.0, seed: int = 0, mode: str = "work",
-                 tuning: Optional[Sequence[float]] = None, lin_vel_max: float = 1.5):
+                 tuning: Optional[Sequence[float]] = None, lin_vel_max: float = 1.5, warm_start: bool = False):
         import torch
         self.torch = torch
         self.cfg = config
@@ -71,6 +71,7 @@ class BatchEvaluator:
         self.hcount = torch.ones(B, self.H, dtype=torch.long, device=self.dev)
         self.polys = T(map_polygons)                               # [M,4,2]
         self.stagger = float(human_stagger)
+        self.warm_start = warm_start       # row f4 (extension): shifted previous solution as the initial guess
         self.gen = torch.Generator(device=self.dev).manual_seed(seed)
         scale = {"safe": 0.2, "work": 0.8, "super": 1.0}[mode]
         self.base_speed = lin_vel_max * scale
@@ -207,7 +208,9 @@ class BatchEvaluator:
             if record is not None:
                 rec = dict(robot=self.robot.cpu().numpy(), humans=self.humans.cpu().numpy(), alive=alive.cpu().numpy(),
                            y_in=self.y.cpu().numpy())
-            self.h.solve_raw(self.dt, self.P, B, self.U, status=self.status, y=self.y, y_is_input=kt > 0, sync=False)
+            u0 = torch.cat([self.U[:, 2:], self.U[:, -2:]], dim=1).contiguous() if (self.warm_start and kt > 0) else None
+            self.h.solve_raw(self.dt, self.P, B, self.U, status=self.status, u0=u0, y=self.y, y_is_input=kt > 0,
+                             sync=False)
             if record is not None:
                 rec.update(P=self.P.cpu().numpy(), U=self.U.cpu().numpy())
                 record.append(rec)

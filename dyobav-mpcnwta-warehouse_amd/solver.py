@@ -77,10 +77,13 @@ class Solver:
     (``keep_multipliers=False`` resets them to zero every call instead).
     """
 
-    def __init__(self, config: Optional[NmpcConfigStruct] = None, dtype=np.float64, keep_multipliers: bool = True):
+    def __init__(self, config: Optional[NmpcConfigStruct] = None, dtype=np.float64, keep_multipliers: bool = True,
+                 warm_start: bool = False):
         self.config = config if config is not None else default_config_struct()
         self.dtype = np.dtype(dtype)
         self.keep_multipliers = keep_multipliers
+        self.warm_start = warm_start      # row f4: shifted previous solution as the initial guess when none is passed
+        self._u_prev = None
         self._handle = Handle(self.config)
         self.num_parameters = self._handle.np_
         self.num_decision_variables = self._handle.n
@@ -98,6 +101,8 @@ class Solver:
             if u0.shape[1] != n:
                 print(f"1700 -> wrong length of initial guess: expected {n}, got {u0.shape[1]}")
                 return None
+        elif self.warm_start and self._u_prev is not None:
+            u0 = shift_solution(self._u_prev)
         if initial_lagrange_multipliers is not None:
             y = np.asarray(initial_lagrange_multipliers, dtype=self.dtype).reshape(1, -1).copy()
             if y.shape[1] != n:
@@ -116,6 +121,7 @@ class Solver:
             print("2000 -> Problem solution failed")
             return None
         self._y = out["y"].astype(self.dtype)
+        self._u_prev = out["U"].astype(self.dtype)
         info = out["info"][0]
         return OptimizerSolution(
             exit_status=EXIT_STATUS_NAMES[status], num_outer_iterations=int(out["iters"][0, 0]),
@@ -124,8 +130,33 @@ class Solver:
             solve_time_ms=wall_ms, penalty=float(info[3]), solution=[float(v) for v in out["U"][0]],
             lagrange_multipliers=[float(v) for v in out["y"][0]], cost=float(out["cost"][0]))
 
+    def run_many(self, P) -> list:
+        """All rows of ``P`` in one launch (zero initial guess and multipliers each, like independent ``run`` calls
+        on fresh solver objects); one ``OptimizerSolution`` per row. Used by the ``RunBatch`` request of ``tcp``."""
+        P = np.asarray(P, dtype=self.dtype).reshape(-1, self.num_parameters)
+        tic = time.perf_counter()
+        out = self._handle.solve(P, dtype=self.dtype)
+        wall_ms = (time.perf_counter() - tic) * 1e3
+        sols = []
+        for b in range(P.shape[0]):
+            info = out["info"][b]
+            sols.append(OptimizerSolution(
+                exit_status=EXIT_STATUS_NAMES[int(out["status"][b])], num_outer_iterations=int(out["iters"][b, 0]),
+                num_inner_iterations=int(out["iters"][b, 1]), last_problem_norm_fpr=float(info[0]),
+                f1_infeasibility=float(info[2] / info[3]) if info[3] else float(info[2]), f2_norm=float(info[1]),
+                solve_time_ms=wall_ms, penalty=float(info[3]), solution=[float(v) for v in out["U"][b]],
+                lagrange_multipliers=[float(v) for v in out["y"][b]], cost=float(out["cost"][b])))
+        return sols
+
     def close(self):
         self._handle.close()
+
+
+def shift_solution(U: np.ndarray) -> np.ndarray:
+    """Receding-horizon shift of solutions ``[B, 2N]`` laid out (v0, w0, v1, w1, ...): drop the applied action, repeat
+    the last one. Not something the reference does (``trajectory_tracker.py:362`` passes no initial guess)."""
+    U = np.asarray(U)
+    return np.concatenate([U[:, 2:], U[:, -2:]], axis=1)
 
 
 def solver(config: Optional[NmpcConfigStruct] = None, dtype=np.float64, **kwargs) -> Solver:

@@ -33,9 +33,14 @@ class TrajectoryTracker:
         self.set_work_mode(mode="safe")
         self.set_obstacle_weights(stc_weights=10, dyn_weights=10)
         self.use_tcp = use_tcp
-        if use_tcp:
-            raise NotImplementedError("the TCP/JSON solver server of OpEn is not part of the GPU path")
-        self.solver = self._load_solver(solver_factory)
+        if use_tcp:     # reference :62-66: OptimizerTcpManager(solver_path).start(); ping()
+            from .tcp import OptimizerTcpManager
+            path = os.path.join("", self.config.build_directory, self.config.optimizer_name)
+            self.mng = OptimizerTcpManager(path, solver_factory=lambda: self._load_solver(solver_factory))
+            self.mng.start()
+            self.mng.ping()
+        else:
+            self.solver = self._load_solver(solver_factory)
 
     # ------------------------------------------------------------------------------------------------------
     def _load_solver(self, solver_factory):
@@ -219,10 +224,19 @@ class TrajectoryTracker:
         return actions, pred_states, ref_states, cost
 
     def run_solver(self, parameters: list, state: np.ndarray, take_steps: int = 1):
-        """Solve, then roll the returned controls out with the motion model (reference :339-383)."""
-        sol = self.solver.run(parameters)
-        if sol is None:
-            raise RuntimeError("MPC Solver error: the solver returned no solution")
+        """Solve, then roll the returned controls out with the motion model (reference :339-383; over the socket
+        :385-400)."""
+        if self.use_tcp:
+            resp = self.mng.call(parameters)
+            if not resp.is_ok():
+                err = resp.get()
+                self.mng.kill()
+                raise RuntimeError(f"MPC Solver error: [{err.code}]{err.message}")
+            sol = resp.get()
+        else:
+            sol = self.solver.run(parameters)
+            if sol is None:
+                raise RuntimeError("MPC Solver error: the solver returned no solution")
         u, nu = sol.solution, self.nu
         taken = [self.motion_model(state, np.array(u[i * nu:(i + 1) * nu]), self.ts) for i in range(take_steps)]
         pred = [taken[-1]]

@@ -1,0 +1,80 @@
+"""GPU tests of row f4: the real solver behind the TCP/JSON front end, and the warm-start policy."""
+import numpy as np
+import pytest
+
+import dyobav_mpcnwta_warehouse_amd as nm
+from dyobav_mpcnwta_warehouse_amd import tcp
+from dyobav_mpcnwta_warehouse_amd.evaluate import BatchEvaluator
+from dyobav_mpcnwta_warehouse_amd.solver import Solver, shift_solution
+
+from test_gpu_evaluate import _scenarios
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(B, seed=3):
+    return nm.scenarios.make_batch(B, seed=seed, ped_mode="oncoming")
+
+
+def test_socket_answers_equal_in_process_answers():
+    P = _batch(6).astype(np.float64)
+    mng = tcp.OptimizerTcpManager(solver_factory=lambda: Solver(nm.default_config_struct(), keep_multipliers=False))
+    mng.start()
+    ref = Solver(nm.default_config_struct(), keep_multipliers=False)
+    try:
+        assert mng.ping() == {"Pong": 1}
+        for b in range(3):
+            r, s = mng.call(P[b].tolist()), ref.run(P[b].tolist())
+            assert r.is_ok()
+            g = r.get()
+            assert g.solution == s.solution and g.cost == s.cost and g.exit_status == s.exit_status   # json round trip is exact
+            assert g.num_inner_iterations == s.num_inner_iterations and g.lagrange_multipliers == s.lagrange_multipliers
+            assert g.f1_infeasibility == s.f1_infeasibility and g.penalty == s.penalty
+        # explicit initial guess / multipliers / penalty reach the kernel
+        u0, y0 = [0.3, 0.0] * 20, [0.1] * 40
+        r = mng.call(P[3].tolist(), initial_guess=u0, initial_y=y0, initial_penalty=50.0).get()
+        s = ref.run(P[3].tolist(), initial_guess=u0, initial_lagrange_multipliers=y0, initial_penalty=50.0)
+        assert r.solution == s.solution and r.num_inner_iterations == s.num_inner_iterations
+        # batch extension: one launch, same answers as one-by-one
+        out = mng.call_batch(P.tolist())
+        for b in range(6):
+            assert out[b].get().solution == ref.run(P[b].tolist()).solution
+        assert mng.call(P[0, :100].tolist()).get().code == 1600
+    finally:
+        mng.kill()
+        ref.close()
+
+
+def test_warm_start_policy_of_the_single_solver():
+    """``Solver(warm_start=True)`` is exactly "pass the shifted previous solution as initial_guess" (the benefit is
+    a closed-loop property, measured in the next test)."""
+    P = _batch(4, seed=9).astype(np.float64)
+    for b in range(4):
+        cold, warm = Solver(nm.default_config_struct()), Solver(nm.default_config_struct(), warm_start=True)
+        c1, w1 = cold.run(P[b].tolist()), warm.run(P[b].tolist())
+        assert c1.solution == w1.solution                               # first call: nothing to shift
+        np.testing.assert_array_equal(warm._u_prev[0], np.array(w1.solution))
+        w2 = warm.run(P[b].tolist())
+        w2b = cold.run(P[b].tolist(), initial_guess=shift_solution(np.array([w1.solution]))[0].tolist())
+        assert w2.solution == w2b.solution and w2.num_inner_iterations == w2b.num_inner_iterations
+        u_own = [0.2, 0.0] * 20
+        assert warm.run(P[b].tolist(), initial_guess=u_own).solution == cold.run(P[b].tolist(), initial_guess=u_own).solution
+        cold.close(), warm.close()
+
+
+def test_warm_started_closed_loop_is_cheaper_and_as_good():
+    rng = np.random.default_rng(21)
+    B = 256
+    boxes, starts, paths, hstart, hpath = _scenarios(B, rng)
+    res = {}
+    for warm in (False, True):
+        ev = BatchEvaluator(nm.default_config_struct(), starts, paths, hstart, hpath, boxes, dtype=np.float32,
+                            warm_start=warm)
+        res[warm] = ev.run(max_steps=60)
+        ev.close()
+    cold, warm = res[False], res[True]
+    print("complete", cold.complete.mean(), warm.complete.mean(), "kernel ms", sum(cold.solve_ms), sum(warm.solve_ms),
+          "mean steps", cold.steps.mean(), warm.steps.mean(), "deviation", np.nanmean(cold.deviation[:, 0]),
+          np.nanmean(warm.deviation[:, 0]))
+    assert warm.complete.mean() >= cold.complete.mean() - 0.05
+    assert sum(warm.solve_ms) < sum(cold.solve_ms)

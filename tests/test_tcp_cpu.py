@@ -1,0 +1,144 @@
+"""CPU tests of the TCP/JSON front end (row f4): wire format, error codes and the tracker's use_tcp path, with a
+scripted solver behind the socket (no GPU). The protocol is restated from opengen's published client/server pair and
+is not pinned by anything in the reference ("wire format unpinned", see the module docstring)."""
+import json
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+
+from dyobav_mpcnwta_warehouse_amd import tcp
+from dyobav_mpcnwta_warehouse_amd.configs import CircularRobotSpecification, MpcConfiguration
+from dyobav_mpcnwta_warehouse_amd.motion_model import UnicycleModel
+from dyobav_mpcnwta_warehouse_amd.solver import OptimizerSolution, shift_solution
+from dyobav_mpcnwta_warehouse_amd.trajectory_tracker import TrajectoryTracker
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "config", "mpc_fast.yaml")
+
+
+class _Scripted:
+    num_parameters, num_decision_variables = 2778, 40
+
+    def __init__(self):
+        self.calls = []
+
+    def _sol(self, p, n):
+        u = [0.5 + 0.02 * k + 0.1 * n if j == 0 else 0.1 - 0.01 * k for k in range(20) for j in range(2)]
+        return OptimizerSolution(exit_status="Converged", num_outer_iterations=2, num_inner_iterations=7 + n,
+                                 last_problem_norm_fpr=1e-5, f1_infeasibility=2e-5, f2_norm=0.0, solve_time_ms=1.25,
+                                 penalty=50.0, solution=u, lagrange_multipliers=[0.5] * 40, cost=12.5 * n + float(p[0]))
+
+    def run(self, p, initial_guess=None, initial_lagrange_multipliers=None, initial_penalty=None):
+        self.calls.append((initial_guess, initial_lagrange_multipliers, initial_penalty))
+        if p[0] == -999.0:
+            return None
+        return self._sol(p, len(self.calls))
+
+    def run_many(self, P):
+        return [self._sol(p, i) for i, p in enumerate(P)]
+
+
+@pytest.fixture
+def manager():
+    fake = _Scripted()
+    mng = tcp.OptimizerTcpManager("mpc_solver/navi_fast", solver_factory=lambda: fake)
+    mng.start()
+    yield mng, fake
+    mng.kill()
+
+
+def _raw(mng, text):
+    with socket.create_connection((mng.ip, mng.port), timeout=10) as s:
+        s.sendall(text.encode())
+        s.shutdown(socket.SHUT_WR)
+        data = b""
+        while True:
+            c = s.recv(4096)
+            if not c:
+                break
+            data += c
+    return json.loads(data.decode())
+
+
+def test_ping_run_and_optional_fields(manager):
+    mng, fake = manager
+    assert mng.ping() == {"Pong": 1}
+    p = [0.25] + [0.0] * 2777
+    r = mng.call(p)
+    assert r.is_ok()
+    s = r.get()
+    assert s.exit_status == "Converged" and s.num_inner_iterations == 8 and s.cost == 12.5 + 0.25
+    assert s.f1_infeasibility == 2e-5 and s.penalty == 50.0 and len(s.solution) == 40 and len(s.lagrange_multipliers) == 40
+    assert r["solve_time_ms"] == 1.25
+    assert fake.calls[-1] == (None, None, None)
+    r = mng.call(p, initial_guess=[0.1] * 40, initial_y=[0.0] * 40, initial_penalty=25)
+    assert r.is_ok() and fake.calls[-1] == ([0.1] * 40, [0.0] * 40, 25.0)
+    # the raw document a non-Python caller sends / receives (field names of the generated server)
+    d = _raw(mng, '{"Run" : {"parameter": [' + ",".join(map(str, p)) + ']}}')
+    assert set(d) == {"exit_status", "num_outer_iterations", "num_inner_iterations", "last_problem_norm_fpr",
+                      "delta_y_norm_over_c", "f2_norm", "solve_time_ms", "penalty", "solution", "lagrange_multipliers",
+                      "cost"}
+
+
+def test_error_documents(manager):
+    mng, _ = manager
+    r = mng.call([0.0] * 10)
+    assert not r.is_ok() and r.get().code == 1600 and "parameters" in r.get().message
+    p = [0.0] * 2778
+    assert mng.call(p, initial_guess=[0.0] * 3).get().code == 1700
+    assert mng.call(p, initial_y=[0.0] * 3).get().code == 1800
+    assert mng.call([-999.0] + [0.0] * 2777).get().code == 2000
+    for bad in ('{"Walk": 1}', "not json", '{"Run": 5}', "[1, 2]"):
+        d = _raw(mng, bad)
+        assert d["type"] == "Error" and d["code"] == 1000
+    assert mng.ping() == {"Pong": 1}                     # the server survives bad requests
+
+
+def test_batch_request_extension(manager):
+    mng, _ = manager
+    P = [[float(i)] + [0.0] * 2777 for i in range(5)]
+    out = mng.call_batch(P)
+    assert len(out) == 5 and all(r.is_ok() for r in out)
+    assert [r.get().cost for r in out] == [12.5 * i + i for i in range(5)]
+    assert not mng.call_batch([[0.0] * 7])[0].is_ok()
+
+
+def test_tracker_over_tcp_equals_tracker_in_process():
+    """reference trajectory_tracker.py:385-400 vs :361-383: same numbers whichever way the solver is reached."""
+    mpc, rob = MpcConfiguration.from_yaml(CFG), CircularRobotSpecification.from_yaml(CFG)
+    outs = []
+    for use_tcp in (False, True):
+        tr = TrajectoryTracker(mpc, rob, use_tcp=use_tcp, verbose=False, solver_factory=_Scripted)
+        tr.load_motion_model(UnicycleModel(rob.ts))
+        tr.load_init_states(np.array([0.0, 0.0, 0.0]), np.array([5.0, 3.0, 1.57]))
+        tr.set_work_mode("work")
+        tr.set_ref_trajectory([(5.0, 0.0), (5.0, 3.0)])
+        steps = [tr.run_step([0.0] * 120, [0.0] * 1890, mode="work") for _ in range(3)]
+        outs.append((steps, np.array(tr.past_states), tr.cost_timelist))
+        if use_tcp:
+            tr.mng.kill()
+    for (a, p, r, c), (a2, p2, r2, c2) in zip(outs[0][0], outs[1][0]):
+        np.testing.assert_array_equal(np.array(a), np.array(a2))
+        np.testing.assert_array_equal(np.array(p), np.array(p2))
+        np.testing.assert_array_equal(r, r2)
+        assert c == c2
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2]
+
+
+def test_tracker_over_tcp_raises_and_kills_on_error():
+    mpc, rob = MpcConfiguration.from_yaml(CFG), CircularRobotSpecification.from_yaml(CFG)
+    tr = TrajectoryTracker(mpc, rob, use_tcp=True, verbose=False, solver_factory=_Scripted)
+    tr.load_motion_model(UnicycleModel(rob.ts))
+    with pytest.raises(RuntimeError, match=r"\[1600\]"):
+        tr.run_solver([0.0] * 5, np.zeros(3))
+    with pytest.raises(OSError):
+        tr.mng.ping()                                    # the server was told to stop (reference :396)
+
+
+def test_shift_solution():
+    U = np.arange(12.0).reshape(2, 6)
+    np.testing.assert_array_equal(shift_solution(U), [[2, 3, 4, 5, 4, 5], [8, 9, 10, 11, 10, 11]])
