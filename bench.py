@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="override the per-GPU batch (default: BASELINE's)")
     ap.add_argument("--dtype", choices=("f32", "f64"), default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency-waves", type=int, default=0,
+                    help="nmpc_config.latency_waves: 0 = automatic (library default), 1 = one wavefront per instance, "
+                         "4 = latency mode")
     args = ap.parse_args()
 
     # stdout must carry exactly ONE JSON line: RCCL / HIP libraries print banners and warnings on fd 1, so keep a
@@ -122,6 +125,7 @@ def main():
     # capacity hint: the workload has n_ped x n_hyp predicted-obstacle hypotheses, the remaining Ndynobs slots are
     # the reference's zero padding (mpc_interface.py:82-88); fewer provisioned rows -> less LDS per instance
     cfg.max_active_dynobs = spec["n_ped"] * spec["n_hyp"]
+    cfg.latency_waves = args.latency_waves
     h = nm.Handle(cfg)
     stream = torch.cuda.current_stream()
     h.set_stream(stream.cuda_stream)
@@ -194,7 +198,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "batch_per_gpu": B, "N_hor": layout.N,
                        "Ndynobs": layout.Ndyn, "Nstcobs": layout.Nstc, "Nother": layout.Nother,
-                       "np": layout.np_, "max_active_dynobs": int(cfg.max_active_dynobs), "sharding": f"{world} x independent shards, all_gather of U"
+                       "np": layout.np_, "max_active_dynobs": int(cfg.max_active_dynobs), "latency_waves": int(cfg.latency_waves), "sharding": f"{world} x independent shards, all_gather of U"
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS,

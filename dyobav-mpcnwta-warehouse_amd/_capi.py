@@ -41,6 +41,7 @@ class NmpcConfigStruct(C.Structure):
         ("lip_eps_f64", C.c_double), ("lip_delta_f64", C.c_double),
         ("lip_eps_f32", C.c_double), ("lip_delta_f32", C.c_double),
         ("cbfgs_alpha", C.c_double), ("cbfgs_epsilon", C.c_double), ("sy_epsilon", C.c_double),
+        ("latency_waves", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 # NMPC_HIP_LIBRARY: load an alternative build of the same C ABI (A/B tests of kernel variants)
 LIB_PATH = os.environ.get("NMPC_HIP_LIBRARY") or os.path.join(PKG_DIR, "libnmpc_hip.so")
 SOURCES = ("nmpc_capi.hip",)
-HEADERS = ("nmpc_device.h", "wave_ops.h", os.path.join("..", "..", "include", "nmpc_hip.h"))
+HEADERS = ("nmpc_device.h", "nmpc_spec.h", "nmpc_assemble.h", "nmpc_hypotheses.h", "wave_ops.h", os.path.join("..", "..", "include", "nmpc_hip.h"))
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
                "-Wall", "-Wno-unused-function")
 

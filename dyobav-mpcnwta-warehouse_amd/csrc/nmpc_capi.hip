@@ -15,6 +15,7 @@
 #include "../../include/nmpc_hip.h"
 #include "nmpc_assemble.h"
 #include "nmpc_device.h"
+#include "nmpc_spec.h"
 #include "nmpc_hypotheses.h"
 
 namespace {
@@ -78,11 +79,16 @@ bool is_device_ptr(const void* ptr)
 struct Layout {
     int np, off_rs, off_rv, off_c0, off_c, off_os, off_od, off_qstc, off_qdyn;
     int lds_alpha, lds_poly, lds_seg, lds_seginv, lds_fl0, lds_fl, lds_iflag, lds_hist, lds_rho, lds_total;
+    int lds_xch, lds_total_spec; // latency mode: exchange area appended behind lds_total
     int dyn_cap;          // obstacle rows provisioned per instance
     bool glb;             // obstacle table streamed from a global workspace instead of LDS
     long long ws_stride;  // workspace elements per instance (glb only)
 };
 
+#ifndef NMPC_SPEC_WPE_F32
+#define NMPC_SPEC_WPE_F32 3 // wavefronts per SIMD the fp32 latency kernel is compiled for (caps VGPRs at 168)
+#endif
+constexpr int kSpecWaves = 4; // wavefronts per instance in latency mode (nmpc_spec.h)
 constexpr size_t kLdsLimit = 160 * 1024; // bytes of LDS one workgroup may use on gfx950
 
 int round4(int x) { return (x + 3) & ~3; }
@@ -116,6 +122,8 @@ Layout make_layout(const nmpc_config& c, size_t elem_size)
     L.lds_hist = L.lds_iflag + round4(c.Ndynobs);  // int flags / compaction map (an int fits in a T)
     L.lds_rho = L.lds_hist + 4 * nmpc::kMem * N;    // L-BFGS ring: kMem x N x (s_v, s_w, y_v, y_w)
     L.lds_total = L.lds_rho + round4(2 * nmpc::kMem); // rho[kMem], alpha[kMem]
+    L.lds_xch = L.lds_total;                           // 2 buffers x kSpecWaves x (64 lanes x 2 gradient entries + psi)
+    L.lds_total_spec = L.lds_xch + 2 * kSpecWaves * (2 * 64 + 4);
     if (L.glb || (size_t)L.lds_total * elem_size <= kLdsLimit) break;
     L.glb = true; // second attempt: everything but the ellipse table in LDS
     L.ws_stride = (long long)(nmpc::kEllStride + 1) * ne;
@@ -129,6 +137,8 @@ struct nmpc_handle_s {
     nmpc_config cfg;
     Layout lay32, lay64;
     int lps;
+    int n_simd = 0; // SIMDs of the device (4 per CU): latency_waves = 0 picks the wavefront count from B / n_simd
+    bool spec_ok[2] = {true, true}; // [f32, f64]
     template <typename T>
     const Layout& lay() const
     {
@@ -155,6 +165,14 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? NMPC_WPE_F32 : NMPC_WPE_F64))
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     nmpc::solve_instance<T, LPS, GLB>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
+}
+
+// latency mode: kSpecWaves wavefronts per instance, speculative line search (nmpc_spec.h)
+template <typename T, int LPS, bool GLB>
+__global__ __launch_bounds__(64 * kSpecWaves, (sizeof(T) == 4 ? NMPC_SPEC_WPE_F32 : 1)) void solve_spec_kernel(nmpc::KParams<T> kp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    nmpc::solve_instance_spec<T, LPS, GLB>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
 }
 
 template <typename T, int LPS, bool GLB>
@@ -253,6 +271,7 @@ void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k)
     k.lds_hist = L.lds_hist;
     k.lds_rho = L.lds_rho;
     k.lds_total = L.lds_total;
+    k.lds_xch = L.lds_xch;
     k.ts = (T)c.ts;
     k.inv_ts = (T)(1.0 / c.ts);
     k.vmin = (T)c.lin_vel_min;
@@ -293,6 +312,13 @@ SolveFn<T> pick_solve(int lps, bool glb)
     if (glb) return lps == 3 ? solve_kernel<T, 3, true> : lps == 2 ? solve_kernel<T, 2, true> : solve_kernel<T, 1, true>;
     return lps == 3 ? solve_kernel<T, 3, false> : lps == 2 ? solve_kernel<T, 2, false> : solve_kernel<T, 1, false>;
 }
+template <typename T>
+SolveFn<T> pick_solve_spec(int lps, bool glb)
+{
+    if (glb) return lps == 3 ? solve_spec_kernel<T, 3, true> : lps == 2 ? solve_spec_kernel<T, 2, true> : solve_spec_kernel<T, 1, true>;
+    return lps == 3 ? solve_spec_kernel<T, 3, false> : lps == 2 ? solve_spec_kernel<T, 2, false> : solve_spec_kernel<T, 1, false>;
+}
+
 template <typename T>
 EvalFn<T> pick_eval(int lps, bool glb)
 {
@@ -369,10 +395,19 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
     if ((rc = stage_out(h->dinfo, info, (size_t)B * info_row, &k.info, &hinfo))) return rc;
     if (hy && y_is_input) HIP_TRY(hipMemcpyAsync(k.y, y, (size_t)B * n * sizeof(T), hipMemcpyHostToDevice, h->stream));
 
-    const size_t lds_bytes = (size_t)L.lds_total * sizeof(T);
-    SolveFn<T> fn = pick_solve<T>(h->lps, L.glb);
+    // latency mode (several wavefronts per instance) pays off while the batch leaves SIMDs idle
+    // wavefronts per instance: 0 = throughput kernel; > 0 = latency kernel (pays off while the batch leaves SIMDs idle)
+    int lw = h->cfg.latency_waves;
+    // automatic: measured crossovers. fp64 needs > 256 VGPRs = one wavefront per SIMD, so only a quarter
+    // as many 4-wavefront workgroups are resident
+    const int cap = sizeof(T) == 4 ? h->n_simd : h->n_simd / 4;
+    if (lw == 0) lw = B <= cap ? kSpecWaves : B <= 4 * cap ? 2 : 1;
+    int waves = lw == 1 ? 0 : lw < 0 ? 1 : lw > kSpecWaves ? kSpecWaves : lw;
+    if (!h->spec_ok[sizeof(T) == 4 ? 0 : 1]) waves = 0;
+    const size_t lds_bytes = (size_t)(waves ? L.lds_total_spec : L.lds_total) * sizeof(T);
+    SolveFn<T> fn = waves ? pick_solve_spec<T>(h->lps, L.glb) : pick_solve<T>(h->lps, L.glb);
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(fn, dim3(B), dim3(64), lds_bytes, h->stream, k);
+    hipLaunchKernelGGL(fn, dim3(B), dim3(waves ? 64 * waves : 64), lds_bytes, h->stream, k);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
@@ -538,6 +573,13 @@ int set_lds_limit(nmpc_handle_s* h)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_eval<T>(h->lps, L.glb)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
+    const size_t spec_bytes = (size_t)L.lds_total_spec * sizeof(T);
+    if (spec_bytes > kLdsLimit) {
+        h->spec_ok[sizeof(T) == 4 ? 0 : 1] = false; // no room for the exchange area: latency mode unavailable
+    } else if (spec_bytes > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve_spec<T>(h->lps, L.glb)),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)spec_bytes));
+    }
     return 0;
 }
 
@@ -586,6 +628,8 @@ int nmpc_default_config(nmpc_config* c)
     c->cbfgs_alpha = 1.0;
     c->cbfgs_epsilon = 1e-8;
     c->sy_epsilon = 1e-10;
+    c->latency_waves = 0;
+    c->reserved0 = 0;
     return 0;
 }
 
@@ -606,6 +650,8 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
     if (cfg->lbfgs_memory < 1 || cfg->lbfgs_memory > NMPC_LBFGS_MAX_MEMORY)
         return fail(NMPC_ERR_UNSUPPORTED, "lbfgs_memory = %d outside [1, %d]", cfg->lbfgs_memory,
                     NMPC_LBFGS_MAX_MEMORY);
+    if (cfg->latency_waves < -1)
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "latency_waves = %d < -1", cfg->latency_waves);
     if (!(cfg->ts > 0) || cfg->max_outer_iterations < 1 || cfg->max_inner_iterations < 1 ||
         !(cfg->initial_penalty > 0))
         return fail(NMPC_ERR_INVALID_ARGUMENT, "bad ts / iteration caps / initial penalty");
@@ -639,6 +685,11 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
         return fail(NMPC_ERR_HIP, "handle setup: %s", hipGetErrorString(e));
     }
     h->stream = h->own_stream;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device_id) == hipSuccess)
+            h->n_simd = prop.multiProcessorCount * 4; // 4 SIMDs per CU
+    }
     int rc = set_lds_limit<float>(h);
     if (rc == 0) rc = set_lds_limit<double>(h);
     if (rc) {

@@ -1,0 +1,491 @@
+// nmpc_spec.h -- latency mode of the solver: W wavefronts per MPC instance, speculative line search.
+//
+// Small batches (BASELINE configs[1]: B = 1024 = one wavefront per SIMD of an MI355X) are bound by the LATENCY of the
+// slowest instance, not by throughput: a PANOC iteration is a chain of dependent psi evaluations -- one cost-only
+// evaluation for the Lipschitz test and then the line-search candidates tau = 1, 1/2, 1/4, ... one after another
+// (measured on configs[1]: 3.8 candidates per iteration on average, 4.9 for the slowest instances) -- while three
+// quarters of the chip idle once the easy instances have finished.
+//
+// Here a workgroup of W wavefronts owns one instance. All of them run the same solver state machine on the same data
+// (same instructions, same operands => bit-identical state in every wavefront; the tables in LDS are shared), and only
+// the evaluation requests differ: in the first round of an iteration wavefront 0 evaluates psi at the half step (the
+// Lipschitz test) while wavefronts 1..W-1 already evaluate the first W-1 line-search candidates, computed under the
+// assumption that the test passes (it does unless gamma has to be halved, which resets the L-BFGS buffer anyway);
+// later rounds evaluate W candidates at a time. Results (psi, gradient) are exchanged through a double-buffered LDS
+// area, one s_barrier per round, and every wavefront then replays the sequential acceptance logic on them in order.
+// Each candidate is the same function of the same inputs as in the sequential order, the acceptance tests run in the
+// same order on the same numbers, so the results do not depend on W: launched with one wavefront this kernel IS the
+// sequential algorithm, and 2, 3 or 4 wavefronts give BIT-IDENTICAL results (tested); evaluations whose results are
+// never looked at are the price (info[6] = exchange rounds, info[7] = W). solve_instance() -- the throughput kernel
+// for large batches -- is a separate compilation of the same algorithm and agrees with this one to rounding only.
+//
+// Restates the same OpEn pieces as solve_instance (core::panoc, lbfgs, alm); see the notes there.
+#pragma once
+
+#include "nmpc_device.h"
+
+namespace nmpc {
+
+enum SpecPhase : int { SP_INIT_A, SP_INIT_B, SP_LIP, SP_SPEC0, SP_NOLS, SP_LSN, SP_OUTER };
+
+template <typename T, int LPS, bool GLB>
+__device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const int inst, T* lds)
+{
+    // W is a run-time value (workgroup size / 64, at most kMaxSpecWaves) so that every choice of W executes the very
+    // same machine code: with the compiler's default contraction (-ffp-contract=fast) two instantiations of this
+    // function would fuse multiplies and adds differently and agree only to rounding.
+    const int W = (int)(blockDim.x >> 6);
+    const T GAMMA_L = T(0.95), LIP_EPS_UPD = T(1e-6), MIN_L = T(1e-10), MAX_L = T(1e9);
+    const int MAX_LIP = 10, MAX_LS = 10;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+
+    Instance<T, LPS, GLB> I(kp, kp.P + (size_t)inst * kp.np, lds, GLB ? kp.ws + (long long)inst * kp.ws_stride : nullptr);
+    if (!I.load()) { // NMPC_CAPACITY_EXCEEDED (uniform over the workgroup)
+        const T nan = __builtin_nanf("");
+        if (wave == 0) {
+            if (I.lead) {
+                kp.U[(size_t)inst * 2 * kp.N + 2 * I.k] = nan;
+                kp.U[(size_t)inst * 2 * kp.N + 2 * I.k + 1] = nan;
+            }
+            if (I.lane == 0) {
+                if (kp.cost) kp.cost[inst] = nan;
+                if (kp.status) kp.status[inst] = 4;
+                if (kp.iters) kp.iters[2 * inst] = kp.iters[2 * inst + 1] = 0;
+                if (kp.info)
+                    for (int i = 0; i < 8 + kProfSlots; ++i) kp.info[(size_t)inst * (8 + kProfSlots) + i] = 0;
+            }
+        }
+        return;
+    }
+    const int N = kp.N, n2 = kp.Ndyn;
+    const int kk = I.act ? I.k : 0;
+    const bool lead = I.lead;
+
+    T uv = 0, uw = 0, yv = 0, yw = 0;
+    if (kp.u0) {
+        uv = kp.u0[(size_t)inst * 2 * N + 2 * kk];
+        uw = kp.u0[(size_t)inst * 2 * N + 2 * kk + 1];
+    }
+    if (kp.y && kp.y_is_input) {
+        yv = kp.y[(size_t)inst * 2 * N + kk];
+        yw = kp.y[(size_t)inst * 2 * N + N + kk];
+    }
+    if (!I.act) uv = uw = yv = yw = 0;
+    T c = kp.c0v ? kp.c0v[inst] : kp.c_init;
+
+    // PANOC cache (same names as solve_instance)
+    T gv = 0, gw = 0, gpv = 0, gpw = 0, hv = 0, hw = 0, sv = 0, sw = 0, dv = 0, dw = 0, fv = 0, fw = 0, pv = 0, pw = 0;
+    T gamma = 0, inv_gamma = 0, L = 0, sigma = 0, tau = 1, cost_value = 0, norm_fpr = 0, rhs_ls = 0;
+    T akkt_tol = kp.init_tol;
+    int iteration = 0;
+    Quad<T>* hist = reinterpret_cast<Quad<T>*>(lds + kp.lds_hist);
+    T* rho = lds + kp.lds_rho;
+    T* alpha = rho + kMem;
+    T osv = 0, osw = 0, ogv = 0, ogw = 0, lb_gamma = 1;
+    int lb_active = 0, lb_head = 0;
+    bool lb_first = true;
+    T dyn = 0, dyn_plus = 0, f2n = 0, f2n_plus = 0;
+    int alm_iter = 0, inner_total = 0, outer = 1, status = 0;
+    int num_iter = 0, lip_it = 0, nls = 0;
+    bool cont = true;
+    T cost_half = 0, normh = 0, fbe_cur = 0;
+    bool fbe_valid = false;
+    int alg_psi = 0, alg_grad = 0, rounds = 0; // evaluations the sequential algorithm performs / exchange rounds
+
+    // exchange area: 2 buffers x W wavefronts x (64 lanes x (g_v, g_w) + psi, padded to 4). Per lane, not per step:
+    // the LPS lanes of a step hold copies of the step's scalars that may differ in the last bit (each lane's
+    // suffix sum associates differently), and every lane must get exactly what it would have computed itself.
+    const int XS = 2 * 64 + 4;
+    T* xch = lds + kp.lds_xch;
+    int xbuf = 0;
+
+    const T vlo = kp.vmin, vhi = kp.vmax, wlo = -kp.wmax, whi = kp.wmax;
+    auto project = [&](T& a, T& b) {
+        a = tclamp(a, vlo, vhi);
+        b = tclamp(b, wlo, whi);
+    };
+    auto grad_step_half = [&](T bv, T bw) {
+        sv = bv - gamma * gv;
+        sw = bw - gamma * gw;
+        hv = sv;
+        hw = sw;
+        project(hv, hw);
+    };
+    auto reset_cache = [&]() {
+        lb_active = 0;
+        lb_first = true;
+        rhs_ls = 0;
+        tau = 1;
+        L = 0;
+        sigma = 0;
+        cost_value = 0;
+        iteration = 0;
+        gamma = 0;
+        inv_gamma = 0;
+        fbe_valid = false;
+    };
+
+    int phase = SP_INIT_A;
+    T ev = uv, ew = uw, ec = c;
+    T inv_cdiv = T(1) / (c > T(1) ? c : T(1));
+    bool want_grad = true, do_eval = true, exchange = false;
+    T r_psi = 0, r_f2 = 0, r_gv = 0, r_gw = 0;
+
+    // every wavefront evaluates the same request (results used locally, no exchange)
+    auto request_uniform = [&](T a, T b, T cc, bool grad) {
+        ev = a;
+        ew = b;
+        ec = cc;
+        want_grad = grad;
+        do_eval = true;
+        exchange = false;
+    };
+    // line-search candidates nls, nls+1, ... on wavefronts first, first+1, ... (tau is the candidate nls's step)
+    auto request_candidates = [&](int first) {
+        exchange = true;
+        if (wave >= first) {
+            const int off = wave - first;
+            T tw = tau;
+            for (int i = 0; i < off; ++i) tw *= T(0.5);
+            do_eval = nls + off <= MAX_LS; // candidate MAX_LS is accepted unconditionally, nothing lies beyond it
+            ev = ls_point(uv, fv, dv, tw);
+            ew = ls_point(uw, fw, dw, tw);
+            ec = c;
+            want_grad = true;
+        }
+    };
+
+    for (;;) {
+        const T e_icd = ec == c ? inv_cdiv : T(1);
+        if (do_eval) {
+            if (want_grad)
+                I.template eval<true>(ev, ew, ec, e_icd, yv, yw, r_psi, r_f2, r_gv, r_gw);
+            else
+                I.template eval<false>(ev, ew, ec, e_icd, yv, yw, r_psi, r_f2, r_gv, r_gw);
+        }
+        const T* xr = xch + xbuf * (W * XS); // results of this round, one row per wavefront
+        if (exchange) {
+            T* xw = xch + xbuf * (W * XS) + wave * XS;
+            if (do_eval) {
+                if (want_grad) {
+                    xw[2 * I.lane] = r_gv;
+                    xw[2 * I.lane + 1] = r_gw;
+                }
+                if (I.lane == 0) xw[2 * 64] = r_psi;
+            }
+            __syncthreads();
+            xbuf ^= 1; // the next round writes the other buffer: no second barrier needed
+            rounds++;
+        }
+
+        // sequential line-search logic replayed on the exchanged results of wavefronts first..W-1
+        auto process_candidates = [&](int first) -> bool {
+            for (int w = first; w < W; ++w) {
+                pv = ls_point(uv, fv, dv, tau);
+                pw = ls_point(uw, fw, dw, tau);
+                cost_value = xr[w * XS + 2 * 64];
+                gv = xr[w * XS + 2 * I.lane];
+                gw = xr[w * XS + 2 * I.lane + 1];
+                alg_psi++;
+                alg_grad++;
+                grad_step_half(pv, pw);
+                const T t1 = sv - hv, t2 = sw - hw;
+                T d2, gg;
+                I.dot2x2(t1, t2, t1, t2, gv, gw, gv, gw, d2, gg);
+                const T lhs = cost_value - T(0.5) * gamma * gg + T(0.5) * d2 * inv_gamma;
+                fbe_cur = lhs;
+                fbe_valid = true;
+                if (lhs > rhs_ls && nls < MAX_LS) {
+                    tau *= T(0.5);
+                    nls++;
+                    continue;
+                }
+                uv = pv;
+                uw = pw;
+                return true;
+            }
+            return false;
+        };
+
+        bool step_head = false, step_done = false;
+        bool need_dir = false, spec = false; // run the L-BFGS update / direction block below
+
+        if (phase == SP_INIT_A) {
+            alg_psi++;
+            alg_grad++;
+            cost_value = r_psi;
+            gv = r_gv;
+            gw = r_gw;
+            const T e1 = kp.lip_eps * uv, e2 = kp.lip_eps * uw;
+            const T h1 = e1 > kp.lip_delta ? e1 : kp.lip_delta, h2 = e2 > kp.lip_delta ? e2 : kp.lip_delta;
+            normh = tsqrt(I.dot2(h1, h2, h1, h2));
+            if (I.act) {
+                uv += h1;
+                uw += h2;
+            }
+            request_uniform(uv, uw, c, true);
+            phase = SP_INIT_B;
+            continue;
+        } else if (phase == SP_INIT_B) {
+            alg_psi++;
+            alg_grad++;
+            const T d1 = r_gv - gv, d2 = r_gw - gw;
+            L = tsqrt(I.dot2(d1, d2, d1, d2)) / normh;
+            gamma = GAMMA_L / tmax(L, MIN_L);
+            inv_gamma = T(1) / gamma;
+            sigma = (T(1) - GAMMA_L) * T(0.25) * inv_gamma;
+            cost_value = r_psi;
+            grad_step_half(uv, uw);
+            step_head = true;
+        } else if (phase == SP_LIP || phase == SP_SPEC0) {
+            // SP_LIP: every wavefront evaluated psi(u_half) itself; SP_SPEC0: wavefront 0 did
+            cost_half = phase == SP_SPEC0 ? xr[2 * 64] : r_psi;
+            alg_psi++;
+            const T ip = I.dot2(gv, gw, fv, fw);
+            const T rhs = cost_value + LIP_EPS_UPD * tabs(cost_value) - ip +
+                          (GAMMA_L * T(0.5) * inv_gamma) * (norm_fpr * norm_fpr);
+            if (cost_half > rhs && lip_it < MAX_LIP && L < MAX_L) {
+                // gamma is halved: the speculative candidates (if any) are void, continue sequentially
+                lb_active = 0;
+                lb_first = true;
+                L *= T(2);
+                gamma *= T(0.5);
+                inv_gamma *= T(2);
+                fbe_valid = false;
+                grad_step_half(uv, uw);
+                fv = uv - hv;
+                fw = uw - hw;
+                norm_fpr = tsqrt(I.dot2(fv, fw, fv, fw));
+                lip_it++;
+                request_uniform(hv, hw, c, false);
+                phase = SP_LIP;
+                continue;
+            }
+            if (phase == SP_SPEC0) {
+                // the direction and rhs_ls were computed before the round; candidates 0..W-2 are on wavefronts 1..
+                if (process_candidates(1)) {
+                    step_done = true;
+                } else {
+                    request_candidates(0);
+                    phase = SP_LSN;
+                    continue;
+                }
+            } else {
+                need_dir = true; // sequential path: L-BFGS update and direction now
+            }
+        } else if (phase == SP_NOLS) {
+            alg_psi++;
+            alg_grad++;
+            fbe_valid = false;
+            cost_value = r_psi;
+            gv = r_gv;
+            gw = r_gw;
+            grad_step_half(uv, uw);
+            step_done = true;
+        } else if (phase == SP_LSN) {
+            if (process_candidates(0)) {
+                step_done = true;
+            } else {
+                request_candidates(0);
+                continue; // stay in SP_LSN
+            }
+        } else { // SP_OUTER
+            alg_psi++;
+            const T f_u = r_psi;
+            f2n_plus = tsqrt(r_f2);
+            const T v_up = wave_shift_up<LPS>(uv), w_up = wave_shift_up<LPS>(uw);
+            const T vprev = I.k == 0 ? I.vinit : v_up;
+            const T wprev = I.k == 0 ? I.winit : w_up;
+            const T acc = (uv - vprev) * kp.inv_ts, wacc = (uw - wprev) * kp.inv_ts;
+            const T za = acc + yv / c, zw = wacc + yw / c;
+            T ypv = yv + c * (acc - tclamp(za, kp.amin, kp.amax));
+            T ypw = yw + c * (wacc - tclamp(zw, -kp.wamax, kp.wamax));
+            if (!I.act) ypv = ypw = 0;
+            const T e1 = ypv - yv, e2 = ypw - yw;
+            dyn_plus = tsqrt(I.dot2(e1, e2, e1, e2));
+            const T SMALL = Lim<T>::eps;
+            const bool c1 = alm_iter > 0 && dyn_plus <= c * kp.delta_tol + SMALL;
+            const bool c2 = n2 == 0 || f2n_plus <= kp.delta_tol + SMALL;
+            const bool c3 = akkt_tol <= kp.tol + SMALL;
+            bool finished = false, converged = false;
+            if (c1 && c2 && c3) {
+                finished = converged = true;
+            } else {
+                const bool stall = alm_iter == 0 || ((dyn_plus <= kp.suff_dec * dyn + SMALL) &&
+                                                     (n2 == 0 || f2n_plus <= kp.suff_dec * f2n + SMALL));
+                if (!stall) {
+                    c *= kp.pen_update;
+                    inv_cdiv = T(1) / (c > T(1) ? c : T(1));
+                }
+                akkt_tol = tmax(akkt_tol * kp.tol_update, kp.tol);
+                alm_iter++;
+                dyn = dyn_plus;
+                f2n = f2n_plus;
+                yv = ypv;
+                yw = ypw;
+                reset_cache();
+                if (outer >= kp.max_outer) finished = true;
+            }
+            if (finished) {
+                if (!converged) status = 1;
+                bool finite = tfinite(uv) && tfinite(uw) && tfinite(f_u);
+                if (__ballot(!finite) != 0ull) status = 3;
+                if (wave == 0) {
+                    if (lead) {
+                        kp.U[(size_t)inst * 2 * N + 2 * I.k] = uv;
+                        kp.U[(size_t)inst * 2 * N + 2 * I.k + 1] = uw;
+                        if (kp.y) {
+                            kp.y[(size_t)inst * 2 * N + I.k] = yv;
+                            kp.y[(size_t)inst * 2 * N + N + I.k] = yw;
+                        }
+                    }
+                    if (I.lane == 0) {
+                        if (kp.cost) kp.cost[inst] = f_u;
+                        if (kp.status) kp.status[inst] = status;
+                        if (kp.iters) {
+                            kp.iters[2 * inst] = outer;
+                            kp.iters[2 * inst + 1] = inner_total;
+                        }
+                        if (kp.info) {
+                            T* o = kp.info + (size_t)inst * (8 + kProfSlots);
+                            o[0] = norm_fpr;
+                            o[1] = f2n_plus;
+                            o[2] = dyn_plus;
+                            o[3] = c;
+                            o[4] = T(alg_psi);
+                            o[5] = T(alg_grad);
+                            o[6] = T(rounds); // exchange rounds (each = up to W evaluations in parallel)
+                            o[7] = T(W);
+                        }
+                    }
+                }
+                return;
+            }
+            request_uniform(uv, uw, c, true);
+            phase = SP_INIT_A;
+            num_iter = 0;
+            cont = true;
+            outer++;
+            yv = tclamp(yv, T(-1e12), T(1e12));
+            yw = tclamp(yw, T(-1e12), T(1e12));
+            continue;
+        }
+
+        if (step_done) {
+            iteration++;
+            if (!cont) {
+                step_head = false;
+            } else {
+                num_iter++;
+                cont = num_iter < kp.max_inner;
+                step_head = true;
+            }
+        }
+
+        bool inner_exit = !step_head && !need_dir;
+        if (step_head) {
+            if (iteration >= 1) {
+                gpv = gv;
+                gpw = gw;
+            }
+            fv = uv - hv;
+            fw = uw - hw;
+            const T a1 = fv + gamma * (gv - gpv), a2 = fw + gamma * (gw - gpw);
+            T ff, aa;
+            I.dot2x2(fv, fw, fv, fw, a1, a2, a1, a2, ff, aa);
+            norm_fpr = tsqrt(ff);
+            const T akkt = tsqrt(aa);
+            if (norm_fpr < kp.tol && akkt < akkt_tol) {
+                inner_exit = true;
+            } else {
+                lip_it = 0;
+                if (iteration == 0) { // first iteration of an inner solve: no line search, nothing to speculate on
+                    request_uniform(hv, hw, c, false);
+                    phase = SP_LIP;
+                    continue;
+                }
+                need_dir = true;
+                spec = true;
+            }
+        }
+        if (inner_exit) {
+            status = cont ? 0 : 1;
+            inner_total += num_iter;
+            uv = hv;
+            uw = hw;
+            request_uniform(uv, uw, T(0), false);
+            phase = SP_OUTER;
+            continue;
+        }
+
+        // ---- need_dir: lbfgs.update_hessian(gamma_fpr, u), then (iteration > 0) apply_hessian + rhs of the line
+        //      search. spec = true: done BEFORE the Lipschitz test, assuming gamma survives it (otherwise the buffer
+        //      is reset and everything computed here is discarded by the failure branch above).
+        sigma = (T(1) - GAMMA_L) * T(0.25) * inv_gamma;
+        if (lb_first) {
+            lb_first = false;
+            osv = uv;
+            osw = uw;
+            ogv = fv;
+            ogw = fw;
+        } else {
+            const T nsv = uv - osv, nsw = uw - osw, nyv = fv - ogv, nyw = fw - ogw;
+            T ys, ss;
+            I.dot2x2(nsv, nsw, nyv, nyw, nsv, nsw, nsv, nsw, ys, ss);
+            bool ok = true;
+            if (ss <= Lim<T>::min_pos || (kp.sy_eps > T(0) && ys <= kp.sy_eps)) {
+                ok = false;
+            } else if (kp.cbfgs_eps > T(0) && kp.cbfgs_alpha > T(0)) {
+                const T lhs = ys / ss;
+                const T rhs_c = kp.cbfgs_eps * (kp.cbfgs_alpha == T(1) ? norm_fpr : tpow(norm_fpr, kp.cbfgs_alpha));
+                ok = lhs > rhs_c && tfinite(lhs) && tfinite(rhs_c);
+            }
+            if (ok) {
+                osv = uv;
+                osw = uw;
+                ogv = fv;
+                ogw = fw;
+                lb_head = lb_head == 0 ? kp.mem - 1 : lb_head - 1;
+                // all wavefronts write the same values to the same addresses
+                if (lead) hist[lb_head * N + I.k] = Quad<T>{nsv, nsw, nyv, nyw};
+                if (I.lane == 0) rho[lb_head] = T(1) / ys;
+                lb_gamma = ys / I.dot2(nyv, nyw, nyv, nyw);
+                lb_active = lb_active + 1 < kp.mem ? lb_active + 1 : kp.mem;
+                __syncthreads();
+            }
+        }
+        if (iteration == 0) { // update_no_linesearch (only reached from SP_LIP)
+            uv = hv;
+            uw = hw;
+            request_uniform(uv, uw, c, true);
+            phase = SP_NOLS;
+            continue;
+        }
+        lbfgs_apply(I, hist, rho, alpha, N, kk, kp.mem, lb_head, lb_active, lb_gamma, fv, fw, dv, dw);
+        if (!fbe_valid) {
+            const T t1 = sv - hv, t2 = sw - hw;
+            T dist2, gg;
+            I.dot2x2(t1, t2, t1, t2, gv, gw, gv, gw, dist2, gg);
+            fbe_cur = cost_value - T(0.5) * gamma * gg + T(0.5) * dist2 * inv_gamma;
+        }
+        rhs_ls = fbe_cur - sigma * norm_fpr * norm_fpr;
+        tau = 1;
+        nls = 0;
+        if (spec) {
+            request_candidates(1); // wavefronts 1.. : candidates 0..W-2
+            if (wave == 0) {       // wavefront 0: the Lipschitz test's psi(u_half)
+                ev = hv;
+                ew = hw;
+                ec = c;
+                want_grad = false;
+                do_eval = true;
+            }
+            phase = SP_SPEC0;
+        } else {
+            request_candidates(0);
+            phase = SP_LSN;
+        }
+    }
+}
+
+} // namespace nmpc

@@ -1,0 +1,95 @@
+"""GPU test of the latency mode (csrc/nmpc_spec.h): 2, 3 or 4 wavefronts per instance with speculative line search must
+give bit-identical results to the same kernel launched with one wavefront (= the sequential algorithm) -- every
+candidate is the same function of the same inputs and the acceptance logic is replayed in the sequential order. Against
+the throughput kernel (a separate compilation of the same algorithm) the agreement is to rounding, checked the way
+fp32 is checked against fp64."""
+import numpy as np
+import pytest
+
+import dyobav_mpcnwta_warehouse_amd as nm
+from dyobav_mpcnwta_warehouse_amd.scenarios import ParamLayout
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(cfg, P, dtype, waves, **kw):
+    cfg.latency_waves = waves
+    h = nm.Handle(cfg)
+    out = h.solve(P.astype(dtype), dtype=dtype, **kw)
+    h.close()
+    return out
+
+
+def _same(a, b):
+    for key in ("U", "cost", "status", "iters", "y"):
+        assert np.array_equal(a[key], b[key], equal_nan=True), key
+    assert np.array_equal(a["info"][:, :6], b["info"][:, :6])          # fpr, f2, dy, c, #psi, #grad (algorithmic)
+    assert (a["info"][:, 7] == 1).all() and (b["info"][:, 7] > 1).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kw", [dict(seed=31), dict(seed=32, ped_mode="oncoming"), dict(seed=33, n_ped=0, n_boxes=0),
+                                dict(seed=34, n_ped=3, n_hyp=5, n_boxes=2)])
+def test_latency_mode_is_bit_identical(dtype, kw):
+    P = nm.scenarios.make_batch(96, **kw)
+    cfg = nm.default_config_struct()
+    a = _solve(cfg, P, dtype, -1)
+    for waves in (2, 3, 4):
+        b = _solve(cfg, P, dtype, waves)
+        _same(a, b)
+        assert (b["info"][:, 7] == waves).all()
+        assert (b["info"][:, 6] < b["info"][:, 4]).all()        # fewer rounds than sequential evaluations
+    assert (a["status"] == 0).any() or kw.get("ped_mode") is None
+
+
+def test_latency_mode_with_inputs_and_capacity_hint():
+    P = nm.scenarios.make_batch(64, seed=35, ped_mode="oncoming")
+    rng = np.random.default_rng(0)
+    u0 = rng.uniform(-0.2, 0.8, (64, 40))
+    y0 = rng.uniform(-1, 1, (64, 40))
+    c0 = rng.uniform(5, 200, 64)
+    cfg = nm.default_config_struct()
+    cfg.max_active_dynobs = 10
+    for dtype in (np.float32, np.float64):
+        a = _solve(cfg, P, dtype, -1, u0=u0.astype(dtype), y0=y0.astype(dtype), c0=c0.astype(dtype))
+        b = _solve(cfg, P, dtype, 4, u0=u0.astype(dtype), y0=y0.astype(dtype), c0=c0.astype(dtype))
+        _same(a, b)
+    cfg.max_active_dynobs = 4                                            # capacity exceeded: same loud failure
+    a, b = _solve(cfg, P, np.float32, -1), _solve(cfg, P, np.float32, 4)
+    assert (a["status"] == 4).all() and (b["status"] == 4).all() and np.isnan(b["U"]).all()
+
+
+def test_latency_mode_other_dimensions():
+    # N = 30 (2 lanes per step), N = 40 with the obstacle table in the global workspace (1 lane per step)
+    for N, Ndyn, B in ((30, 12, 24), (40, 160, 6)):
+        lay = ParamLayout(N=N, Ndyn=Ndyn)
+        P = nm.scenarios.make_batch(B, lay, seed=36, n_ped=2, n_hyp=3, ped_mode="oncoming")
+        cfg = nm.default_config_struct()
+        cfg.N_hor, cfg.Ndynobs = N, Ndyn
+        cfg.max_inner_iterations, cfg.max_outer_iterations = 60, 4
+        _same(_solve(cfg, P, np.float32, -1), _solve(cfg, P, np.float32, 4))
+
+
+def test_automatic_choice_follows_batch_size():
+    cfg = nm.default_config_struct()
+    cfg.latency_waves = 0
+    h = nm.Handle(cfg)
+    small = h.solve(nm.scenarios.make_batch(32, seed=37).astype(np.float32), dtype=np.float32)
+    mid = h.solve(nm.scenarios.make_batch(2048, seed=37, n_ped=0, n_boxes=0).astype(np.float32), dtype=np.float32)
+    big = h.solve(nm.scenarios.make_batch(8192, seed=37, n_ped=0, n_boxes=0).astype(np.float32), dtype=np.float32)
+    h.close()
+    assert (small["info"][:, 7] == 4).all() and (mid["info"][:, 7] == 2).all() and (big["info"][:, 7] == 0).all()
+
+
+def test_latency_kernel_agrees_with_throughput_kernel_to_rounding():
+    """Separate compilations of the same algorithm: same exit status and iterates to solver accuracy on instances
+    that converge (fp64, Lipschitz step 1e-4: the parity protocol of DESIGN.md)."""
+    P = nm.scenarios.make_batch(256, seed=38, ped_mode="oncoming")
+    cfg = nm.default_config_struct()
+    cfg.lip_eps_f64 = cfg.lip_delta_f64 = 1e-4
+    a, b = _solve(cfg, P, np.float64, 1), _solve(cfg, P, np.float64, 4)
+    conv = (a["status"] == 0) & (b["status"] == 0)
+    assert conv.sum() >= 16 and (a["status"] == b["status"]).mean() > 0.9
+    d = np.abs(a["U"] - b["U"]).max(axis=1)[conv]
+    print("throughput vs latency kernel, converged:", conv.sum(), "median", np.median(d), "q90", np.quantile(d, 0.9), "max", d.max())
+    assert np.median(d) < 1e-9 and np.quantile(d, 0.9) < 1e-4
