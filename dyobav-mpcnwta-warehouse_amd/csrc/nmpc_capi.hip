@@ -155,7 +155,7 @@ namespace {
 
 // second launch-bound argument = minimum waves per SIMD; it caps the register allocation (512 / waves)
 #ifndef NMPC_WPE_F32
-#define NMPC_WPE_F32 2
+#define NMPC_WPE_F32 3
 #endif
 #ifndef NMPC_WPE_F64
 #define NMPC_WPE_F64 1

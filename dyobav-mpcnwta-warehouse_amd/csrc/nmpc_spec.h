@@ -79,8 +79,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     T akkt_tol = kp.init_tol;
     int iteration = 0;
     Quad<T>* hist = reinterpret_cast<Quad<T>*>(lds + kp.lds_hist);
-    T* rho = lds + kp.lds_rho;
-    T* alpha = rho + kMem;
+    LaneVec<T> rho; // rho_i by physical slot (every wavefront keeps its own, identical copy)
     T osv = 0, osw = 0, ogv = 0, ogw = 0, lb_gamma = 1;
     int lb_active = 0, lb_head = 0;
     bool lb_first = true;
@@ -163,6 +162,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             else
                 I.template eval<false>(ev, ew, ec, e_icd, yv, yw, r_psi, r_f2, r_gv, r_gw);
         }
+        NMPC_STAMP(I, 7); // (eval epilogue)
         const T* xr = xch + xbuf * (W * XS); // results of this round, one row per wavefront
         if (exchange) {
             T* xw = xch + xbuf * (W * XS) + wave * XS;
@@ -177,6 +177,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             xbuf ^= 1; // the next round writes the other buffer: no second barrier needed
             rounds++;
         }
+        NMPC_STAMP(I, 8); // exchange: LDS writes + barrier (= waiting for the slowest wavefront of the round)
 
         // sequential line-search logic replayed on the exchanged results of wavefronts first..W-1
         auto process_candidates = [&](int first) -> bool {
@@ -261,6 +262,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 phase = SP_LIP;
                 continue;
             }
+            NMPC_STAMP(I, 9); // Lipschitz test
             if (phase == SP_SPEC0) {
                 // the direction and rhs_ls were computed before the round; candidates 0..W-2 are on wavefronts 1..
                 if (process_candidates(1)) {
@@ -356,6 +358,9 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                             o[5] = T(alg_grad);
                             o[6] = T(rounds); // exchange rounds (each = up to W evaluations in parallel)
                             o[7] = T(W);
+#ifdef NMPC_PROFILE
+                            for (int i = 0; i < kProfSlots; ++i) o[8 + i] = T(I.prof[i]);
+#endif
                         }
                     }
                 }
@@ -371,6 +376,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             continue;
         }
 
+        NMPC_STAMP(I, 10); // phase code (mostly: replaying the line-search tests on the exchanged candidates)
         if (step_done) {
             iteration++;
             if (!cont) {
@@ -408,6 +414,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 spec = true;
             }
         }
+        NMPC_STAMP(I, 11); // step head
         if (inner_exit) {
             status = cont ? 0 : 1;
             inner_total += num_iter;
@@ -448,12 +455,13 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 lb_head = lb_head == 0 ? kp.mem - 1 : lb_head - 1;
                 // all wavefronts write the same values to the same addresses
                 if (lead) hist[lb_head * N + I.k] = Quad<T>{nsv, nsw, nyv, nyw};
-                if (I.lane == 0) rho[lb_head] = T(1) / ys;
+                rho.set(lb_head, T(1) / ys);
                 lb_gamma = ys / I.dot2(nyv, nyw, nyv, nyw);
                 lb_active = lb_active + 1 < kp.mem ? lb_active + 1 : kp.mem;
                 __syncthreads();
             }
         }
+        NMPC_STAMP(I, 12); // L-BFGS update
         if (iteration == 0) { // update_no_linesearch (only reached from SP_LIP)
             uv = hv;
             uw = hw;
@@ -461,7 +469,8 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             phase = SP_NOLS;
             continue;
         }
-        lbfgs_apply(I, hist, rho, alpha, N, kk, kp.mem, lb_head, lb_active, lb_gamma, fv, fw, dv, dw);
+        lbfgs_apply(I, hist, rho, N, kk, kp.mem, lb_head, lb_active, lb_gamma, fv, fw, dv, dw);
+        NMPC_STAMP(I, 13); // two-loop recursion
         if (!fbe_valid) {
             const T t1 = sv - hv, t2 = sw - hw;
             T dist2, gg;

@@ -43,10 +43,16 @@ def problem_small():
     return load_problem_fixture("problem_small.npz")
 
 
+# nmpc_config.latency_waves used by config_for(): test modules that check parity with the oracle run once per solver
+# kernel (1 = throughput kernel, 4 = latency kernel; 0 = the library's automatic choice by batch size)
+KERNEL_MODE = {"latency_waves": 0}
+
+
 def config_for(pr, **overrides):
     """nmpc_config for an oracle.Problem (dims + robot constants) with option overrides."""
     import dyobav_mpcnwta_warehouse_amd as nm
     cfg = nm.default_config_struct()
+    cfg.latency_waves = KERNEL_MODE["latency_waves"]
     cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs = pr.N, pr.Nother, pr.Nstc, pr.Ndyn
     for k in ("ts", "lin_vel_min", "lin_vel_max", "ang_vel_max", "lin_acc_min", "lin_acc_max", "ang_acc_max",
               "vehicle_width", "vehicle_margin", "social_margin"):
