@@ -181,6 +181,11 @@ def main():
         achieved_gbs = bytes_per_solve * B / (k_ms * 1e-3) / 1e9
         ff = flops_forward(layout.N, layout.Nother, layout.Nstc, layout.Ndyn)
         n_psi, n_grad = info[:, 4], info[:, 5]
+        waves = int(info[0, 7])          # 0: throughput kernel; > 0: latency kernel with that many wavefronts per instance
+        tname = "float" if args.dtype == "f32" else "double"
+        lps = h.kernel_info()["lanes_per_step"]
+        kernel_name = (f"solve_spec_kernel<{tname}, LPS={lps}> x {waves} wavefronts per instance (latency mode)" if waves
+                       else f"solve_kernel<{tname}, LPS={lps}> (one wavefront per instance)")
         flops_launch = float(np.sum((n_psi - n_grad) * ff + n_grad * 3 * ff))
         achieved_tf = flops_launch / (k_ms * 1e-3) / 1e12
         out = {
@@ -203,7 +208,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": measured_traffic(args.workload, args.dtype, B),
-                         "kernel": f"solve_kernel<{'float' if args.dtype == 'f32' else 'double'}, LPS={h.kernel_info()['lanes_per_step']}>",
+                         "kernel": kernel_name,
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_per_solve * B,
                          "valu": {"achieved": achieved_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": achieved_tf / VALU_PEAK_TFLOPS,
