@@ -158,7 +158,7 @@ namespace {
 #define NMPC_WPE_F32 3
 #endif
 #ifndef NMPC_WPE_F64
-#define NMPC_WPE_F64 1
+#define NMPC_WPE_F64 2
 #endif
 template <typename T, int LPS, bool GLB>
 __global__ __launch_bounds__(64, (sizeof(T) == 4 ? NMPC_WPE_F32 : NMPC_WPE_F64)) void solve_kernel(nmpc::KParams<T> kp)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? NMPC_WPE_F32 : NMPC_WPE_F64))
 
 // latency mode: kSpecWaves wavefronts per instance, speculative line search (nmpc_spec.h)
 template <typename T, int LPS, bool GLB>
-__global__ __launch_bounds__(64 * kSpecWaves, (sizeof(T) == 4 ? NMPC_SPEC_WPE_F32 : 1)) void solve_spec_kernel(nmpc::KParams<T> kp)
+__global__ __launch_bounds__(64 * kSpecWaves, (sizeof(T) == 4 ? NMPC_SPEC_WPE_F32 : NMPC_WPE_F64)) void solve_spec_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     nmpc::solve_instance_spec<T, LPS, GLB>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
@@ -398,9 +398,9 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
     // latency mode (several wavefronts per instance) pays off while the batch leaves SIMDs idle
     // wavefronts per instance: 0 = throughput kernel; > 0 = latency kernel (pays off while the batch leaves SIMDs idle)
     int lw = h->cfg.latency_waves;
-    // automatic: measured crossovers. fp64 needs > 256 VGPRs = one wavefront per SIMD, so only a quarter
-    // as many 4-wavefront workgroups are resident
-    const int cap = sizeof(T) == 4 ? h->n_simd : h->n_simd / 4;
+    // automatic: measured crossovers. fp64 runs 2 wavefronts per SIMD (256 VGPRs) against 3 in fp32, so
+    // fewer 4-wavefront workgroups are resident
+    const int cap = sizeof(T) == 4 ? h->n_simd : h->n_simd / 2;
     if (lw == 0) lw = B <= cap ? kSpecWaves : B <= 4 * cap ? 2 : 1;
     int waves = lw == 1 ? 0 : lw < 0 ? 1 : lw > kSpecWaves ? kSpecWaves : lw;
     if (!h->spec_ok[sizeof(T) == 4 ? 0 : 1]) waves = 0;

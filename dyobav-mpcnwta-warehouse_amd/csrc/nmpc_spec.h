@@ -154,7 +154,32 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         }
     };
 
+    // The integer / boolean solver state is the same in every lane by construction; telling the compiler so (a
+    // v_readfirstlane each) turns the state machine's control flow into scalar branches instead of lane-mask algebra.
+    auto uni = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+    auto unib = [](bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; };
     for (;;) {
+        phase = uni(phase);
+        iteration = uni(iteration);
+        num_iter = uni(num_iter);
+        nls = uni(nls);
+        lip_it = uni(lip_it);
+        lb_active = uni(lb_active);
+        lb_head = uni(lb_head);
+        alm_iter = uni(alm_iter);
+        outer = uni(outer);
+        inner_total = uni(inner_total);
+        status = uni(status);
+        xbuf = uni(xbuf);
+        rounds = uni(rounds);
+        alg_psi = uni(alg_psi);
+        alg_grad = uni(alg_grad);
+        want_grad = unib(want_grad);
+        do_eval = unib(do_eval);
+        exchange = unib(exchange);
+        lb_first = unib(lb_first);
+        cont = unib(cont);
+        fbe_valid = unib(fbe_valid);
         const T e_icd = ec == c ? inv_cdiv : T(1);
         if (do_eval) {
             if (want_grad)
