@@ -401,7 +401,26 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
     // automatic: measured crossovers. fp64 runs 2 wavefronts per SIMD (256 VGPRs) against 3 in fp32, so
     // fewer 4-wavefront workgroups are resident
     const int cap = sizeof(T) == 4 ? h->n_simd : h->n_simd / 2;
-    if (lw == 0) lw = B <= cap ? kSpecWaves : B <= 4 * cap ? 2 : 1;
+    if (lw == 0) {
+        lw = B <= cap ? kSpecWaves : B <= 4 * cap ? 2 : 1;
+        // Large batches whose LDS tables allow only a few workgroups per CU (e.g. 40 active obstacle rows: 35 KB,
+        // 4 per CU = one wavefront per SIMD): the wavefronts of a latency-kernel workgroup SHARE the instance's
+        // tables, so W of them fill the SIMDs that the throughput kernel leaves empty (measured on configs[2]:
+        // 16.4 k -> 24.0 k solves/s with W = 3). Smallest W that reaches the resident-wavefront limit, if that is
+        // at least 1.5x what the throughput kernel gets.
+        const int max_waves = (sizeof(T) == 4 ? 3 : 2) * 4; // per CU, from the VGPR budget of the kernels
+        const size_t elem = sizeof(T);
+        const int tp = std::min<int>(max_waves, (int)(kLdsLimit / ((size_t)L.lds_total * elem)));
+        const int wg_spec = (int)(kLdsLimit / ((size_t)L.lds_total_spec * elem));
+        int best = tp;
+        for (int w = std::max(lw, 2); w <= kSpecWaves; ++w) {
+            const int res = std::min(max_waves / w, wg_spec) * w;
+            if (2 * res >= 3 * tp && res > best) {
+                best = res;
+                lw = w;
+            }
+        }
+    }
     int waves = lw == 1 ? 0 : lw < 0 ? 1 : lw > kSpecWaves ? kSpecWaves : lw;
     if (!h->spec_ok[sizeof(T) == 4 ? 0 : 1]) waves = 0;
     const size_t lds_bytes = (size_t)(waves ? L.lds_total_spec : L.lds_total) * sizeof(T);
