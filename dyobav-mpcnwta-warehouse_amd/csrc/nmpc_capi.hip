@@ -408,6 +408,9 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
         // tables, so W of them fill the SIMDs that the throughput kernel leaves empty (measured on configs[2]:
         // 16.4 k -> 24.0 k solves/s with W = 3). Smallest W that reaches the resident-wavefront limit, if that is
         // at least 1.5x what the throughput kernel gets.
+        // Obstacle table streamed from the global workspace (GLB): the wavefronts of a workgroup read the same
+        // 236 KB at about the same time, so speculation rides on cache hits (configs[4]: 1.31 k -> 1.58 k solves/s)
+        if (L.glb) lw = kSpecWaves;
         const int max_waves = (sizeof(T) == 4 ? 3 : 2) * 4; // per CU, from the VGPR budget of the kernels
         const size_t elem = sizeof(T);
         const int tp = std::min<int>(max_waves, (int)(kLdsLimit / ((size_t)L.lds_total * elem)));
