@@ -122,6 +122,11 @@ __global__ __launch_bounds__(64) void select_static_kernel(AsmParams<T> a)
     }
 }
 
+#ifndef NMPC_FILL_PER_LANE
+#define NMPC_FILL_PER_LANE 4
+#endif
+constexpr unsigned kFillPerLane = NMPC_FILL_PER_LANE; // elements (independent loads in flight) per lane of the byte mover
+
 template <typename T>
 __device__ __forceinline__ T asm_element(const AsmParams<T>& a, unsigned b, unsigned e, bool& skip)
 {
@@ -147,26 +152,26 @@ __device__ __forceinline__ T asm_element(const AsmParams<T>& a, unsigned b, unsi
     return a.last_u[2 * b + e];
 }
 
-// Byte mover: block = (instance, 1024-element chunk of its row) flattened into blockIdx.x; consecutive lanes handle
+// Byte mover: block = (instance, 256 * kFillPerLane-element chunk of its row) flattened into blockIdx.x; consecutive lanes handle
 // consecutive elements (256 B per wave-instruction on both the load and the store side; the only index division is
-// one scalar division per block), 4 independent loads in flight per lane.
+// one scalar division per block), kFillPerLane independent loads in flight per lane.
 template <typename T>
 __global__ __launch_bounds__(256) void fill_kernel(AsmParams<T> a, unsigned nchunk)
 {
     const unsigned b = blockIdx.x / nchunk, chunk = blockIdx.x - b * nchunk, np = (unsigned)a.np;
     T* row = a.P + (size_t)b * np;
-    T v[4];
-    bool skip[4];
+    T v[kFillPerLane];
+    bool skip[kFillPerLane];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned e = (chunk * 4u + j) * 256u + threadIdx.x;
+    for (int j = 0; j < kFillPerLane; ++j) {
+        const unsigned e = (chunk * kFillPerLane + j) * 256u + threadIdx.x;
         skip[j] = true;
         v[j] = 0;
         if (e < np) v[j] = asm_element(a, b, e, skip[j]);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned e = (chunk * 4u + j) * 256u + threadIdx.x;
+    for (int j = 0; j < kFillPerLane; ++j) {
+        const unsigned e = (chunk * kFillPerLane + j) * 256u + threadIdx.x;
         if (!skip[j]) row[e] = v[j];
     }
 }

@@ -541,7 +541,7 @@ int assemble_params(nmpc_handle_s* h, const nmpc_assemble_args* g, int32_t B, T*
     if (lds > kLdsLimit) return fail(NMPC_ERR_UNSUPPORTED, "%d map polygons do not fit the selection kernel's LDS", a.M);
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(nmpc::select_static_kernel<T>, dim3(B), dim3(64), lds, h->stream, a);
-    const unsigned nchunk = (unsigned)(a.np + 1023) / 1024u;
+    const unsigned per_block = 256u * nmpc::kFillPerLane, nchunk = ((unsigned)a.np + per_block - 1) / per_block;
     if ((unsigned long long)B * nchunk >= (1ull << 31))
         return fail(NMPC_ERR_UNSUPPORTED, "B = %d too large for one assembly call; split the batch", B);
     hipLaunchKernelGGL(nmpc::fill_kernel<T>, dim3((unsigned)B * nchunk), dim3(256), 0, h->stream, a, nchunk);
