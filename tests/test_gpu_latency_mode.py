@@ -67,7 +67,8 @@ def test_latency_mode_other_dimensions():
         cfg = nm.default_config_struct()
         cfg.N_hor, cfg.Ndynobs = N, Ndyn
         cfg.max_inner_iterations, cfg.max_outer_iterations = 60, 4
-        _same(_solve(cfg, P, np.float32, -1), _solve(cfg, P, np.float32, 4))
+        for dtype in (np.float32, np.float64):
+            _same(_solve(cfg, P, dtype, -1), _solve(cfg, P, dtype, 4))
 
 
 def test_automatic_choice_follows_batch_size():
