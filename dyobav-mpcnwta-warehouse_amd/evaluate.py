@@ -49,7 +49,8 @@ class BatchEvaluator:
     def __init__(self, config: _capi.NmpcConfigStruct, robot_starts: np.ndarray, robot_paths: Sequence[Sequence[tuple]],
                  human_starts: np.ndarray, human_paths: np.ndarray, map_polygons: np.ndarray, dtype=np.float64,
                  human_stagger: float = 0.0, seed: int = 0, mode: str = "work",
-                 tuning: Optional[Sequence[float]] = None, lin_vel_max: float = 1.5, warm_start: bool = False):
+                 tuning: Optional[Sequence[float]] = None, lin_vel_max: float = 1.5, warm_start: bool = False,
+                 compact: Optional[bool] = None):
         import torch
         self.torch = torch
         self.cfg = config
@@ -72,6 +73,7 @@ class BatchEvaluator:
         self.polys = T(map_polygons)                               # [M,4,2]
         self.stagger = float(human_stagger)
         self.warm_start = warm_start       # row f4 (extension): shifted previous solution as the initial guess
+        self.compact = (robot_starts.shape[0] > 1024) if compact is None else bool(compact)
         self.gen = torch.Generator(device=self.dev).manual_seed(seed)
         scale = {"safe": 0.2, "work": 0.8, "super": 1.0}[mode]
         self.base_speed = lin_vel_max * scale
@@ -90,6 +92,7 @@ class BatchEvaluator:
         self.dynw = torch.full((self.N,), 10.0, dtype=self.tdt, device=self.dev)
         self.P = torch.empty(B, self.h.np_, dtype=self.tdt, device=self.dev)
         self.U = torch.empty(B, 2 * self.N, dtype=self.tdt, device=self.dev)
+        self._Ua = torch.empty(B, 2 * self.N, dtype=self.tdt, device=self.dev)   # compacted batch of the running scenarios
         self.y = torch.zeros(B, 2 * self.N, dtype=self.tdt, device=self.dev)
         self.status = torch.empty(B, dtype=torch.int32, device=self.dev)
 
@@ -203,16 +206,30 @@ class BatchEvaluator:
             near = dist_goal < self.base_speed * N * ts
             speed = torch.where(near, torch.clamp(dist_goal / N / ts, min=self.lin_vel_max),
                                 torch.full_like(dist_goal, self.base_speed))     # sic: max(), trajectory_tracker.py:308-309
-            self.h.assemble_params(self.dt, B, self.P, last_u.contiguous(), self.robot.contiguous(), refs, speed,
-                                   self.tuning, self.stcw, self.dynw, self.polys, dyn.contiguous())
+            # large batches: only the scenarios still running are assembled and solved (the finished ones keep their
+            # last row of U). Small batches end with their slowest instance anyway, compaction would only add host work.
+            idx = torch.nonzero(alive, as_tuple=False).squeeze(1) if self.compact else None
+            nA = int(idx.numel()) if idx is not None else B
+            full = nA == B
+            sel = (lambda x: x.contiguous()) if full else (lambda x: x.index_select(0, idx).contiguous())
+            Pa = self.P if full else self.P[:nA]
+            Ua = self.U if full else self._Ua[:nA]
+            ya = self.y if full else self.y.index_select(0, idx).contiguous()
+            self.h.assemble_params(self.dt, nA, Pa, sel(last_u), sel(self.robot), sel(refs), sel(speed),
+                                   self.tuning, self.stcw, self.dynw, self.polys, sel(dyn))
             if record is not None:
                 rec = dict(robot=self.robot.cpu().numpy(), humans=self.humans.cpu().numpy(), alive=alive.cpu().numpy(),
                            y_in=self.y.cpu().numpy())
-            u0 = torch.cat([self.U[:, 2:], self.U[:, -2:]], dim=1).contiguous() if (self.warm_start and kt > 0) else None
-            self.h.solve_raw(self.dt, self.P, B, self.U, status=self.status, u0=u0, y=self.y, y_is_input=kt > 0,
-                             sync=False)
+            u0 = None
+            if self.warm_start and kt > 0:
+                u0 = sel(torch.cat([self.U[:, 2:], self.U[:, -2:]], dim=1))
+            self.h.solve_raw(self.dt, Pa, nA, Ua, u0=u0, y=ya, y_is_input=kt > 0, sync=False)
+            if not full:
+                self.U.index_copy_(0, idx, Ua)
+                self.y.index_copy_(0, idx, ya)
             if record is not None:
-                rec.update(P=self.P.cpu().numpy(), U=self.U.cpu().numpy())
+                Pfull = self.P if full else torch.zeros_like(self.P).index_copy_(0, idx, Pa)
+                rec.update(P=Pfull.cpu().numpy(), U=self.U.cpu().numpy())
                 record.append(rec)
             solve_ms.append(self.h.last_kernel_ms())
             raw = self.U[:, :2].clone()

@@ -201,3 +201,23 @@ def test_large_batch_runs_and_reports_metrics():
     # make single trajectories sensitive to rounding, see the teacher-forced test above)
     assert np.isfinite(res.smoothness[ok]).all() and np.quantile(res.deviation[ok, 0], 0.95) < 1.5
     assert (res.steps[ok] <= 60).all() and (res.clearance_dyn[ok] > HUMAN_SIZE).all()
+
+
+def test_compaction_of_finished_scenarios_changes_nothing():
+    """Large batches solve only the scenarios still running; same kernel family, so the results are identical."""
+    rng = np.random.default_rng(14)
+    B = 300
+    boxes, starts, paths, hstart, hpath = _scenarios(B, rng)
+    out = []
+    for compact in (False, True):
+        cfg = nm.default_config_struct()
+        cfg.latency_waves = 2                    # pin the kernel: the automatic choice depends on the batch size
+        ev = BatchEvaluator(cfg, starts, paths, hstart, hpath, boxes, dtype=np.float32, human_stagger=0.2, seed=5,
+                            compact=compact)
+        out.append(ev.run(max_steps=55))
+        ev.close()
+    a, b = out
+    assert a.complete.sum() > 50 and (a.steps < 55).any()                 # scenarios did finish along the way
+    for key in ("collision", "complete", "steps", "trajectory", "clearance", "clearance_dyn", "deviation"):
+        assert np.array_equal(getattr(a, key), getattr(b, key), equal_nan=True), key
+    assert np.array_equal(a.actions, b.actions, equal_nan=True)
