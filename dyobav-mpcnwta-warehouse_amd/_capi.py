@@ -15,7 +15,7 @@ from . import build as _build
 
 EXIT_STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotFiniteComputation",
                      "CapacityExceeded")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class NmpcError(RuntimeError):
@@ -41,7 +41,9 @@ class NmpcConfigStruct(C.Structure):
         ("lip_eps_f64", C.c_double), ("lip_delta_f64", C.c_double),
         ("lip_eps_f32", C.c_double), ("lip_delta_f32", C.c_double),
         ("cbfgs_alpha", C.c_double), ("cbfgs_epsilon", C.c_double), ("sy_epsilon", C.c_double),
-        ("latency_waves", C.c_int32), ("reserved0", C.c_int32),
+        ("latency_waves", C.c_int32), ("akkt_form", C.c_int32),
+        ("max_solver_time_us", C.c_double),
+        ("coop_waves", C.c_int32), ("lbfgs_gram", C.c_int32), ("reserved", C.c_int32 * 2),
     ]
 
 

@@ -299,6 +299,8 @@ void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k)
     k.max_outer = c.max_outer_iterations;
     k.max_inner = c.max_inner_iterations;
     k.mem = c.lbfgs_memory;
+    k.akkt_form = c.akkt_form;
+    k.time_budget = c.max_solver_time_us > 0 ? (long long)(c.max_solver_time_us * 100.0 + 0.5) : 0; // 100 MHz ticks
 }
 
 template <typename T>
@@ -651,7 +653,10 @@ int nmpc_default_config(nmpc_config* c)
     c->cbfgs_epsilon = 1e-8;
     c->sy_epsilon = 1e-10;
     c->latency_waves = 0;
-    c->reserved0 = 0;
+    c->akkt_form = 0;
+    c->max_solver_time_us = 0.0;
+    c->coop_waves = 0;
+    c->lbfgs_gram = 0;
     return 0;
 }
 
@@ -674,6 +679,12 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
                     NMPC_LBFGS_MAX_MEMORY);
     if (cfg->latency_waves < -1)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "latency_waves = %d < -1", cfg->latency_waves);
+    if (cfg->akkt_form != 0 && cfg->akkt_form != 1)
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "akkt_form = %d (0 = OpEn source form, 1 = documented form)", cfg->akkt_form);
+    if (!(cfg->max_solver_time_us >= 0))
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "max_solver_time_us < 0");
+    for (int r : cfg->reserved)
+        if (r != 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "reserved fields must be 0");
     if (!(cfg->ts > 0) || cfg->max_outer_iterations < 1 || cfg->max_inner_iterations < 1 ||
         !(cfg->initial_penalty > 0))
         return fail(NMPC_ERR_INVALID_ARGUMENT, "bad ts / iteration caps / initial penalty");

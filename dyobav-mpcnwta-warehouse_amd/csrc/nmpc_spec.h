@@ -90,6 +90,11 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     T cost_half = 0, normh = 0, fbe_cur = 0;
     bool fbe_valid = false;
     int alg_psi = 0, alg_grad = 0, rounds = 0; // evaluations the sequential algorithm performs / exchange rounds
+    // max_solver_time: wavefront 0 publishes its elapsed real-time ticks with every exchange round, so that all
+    // wavefronts of the workgroup take the same decision (see solve_instance)
+    const long long t_start = kp.time_budget > 0 ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+    int t_now = 0;
+    bool cont_time = true;
 
     // exchange area: 2 buffers x W wavefronts x (64 lanes x (g_v, g_w) + psi, padded to 4). Per lane, not per step:
     // the LPS lanes of a step hold copies of the step's scalars that may differ in the last bit (each lane's
@@ -171,6 +176,8 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         inner_total = uni(inner_total);
         status = uni(status);
         xbuf = uni(xbuf);
+        t_now = uni(t_now);
+        cont_time = unib(cont_time);
         rounds = uni(rounds);
         alg_psi = uni(alg_psi);
         alg_grad = uni(alg_grad);
@@ -198,7 +205,14 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 }
                 if (I.lane == 0) xw[2 * 64] = r_psi;
             }
+            if (kp.time_budget > 0 && wave == 0 && I.lane == 0) {
+                long long el = (long long)__builtin_amdgcn_s_memrealtime() - t_start;
+                if (el > 0x7fffffffll) el = 0x7fffffffll;
+                *reinterpret_cast<int*>(xw + 2 * 64 + 1) = (int)el;
+            }
             __syncthreads();
+            if (kp.time_budget > 0)
+                t_now = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(xr + 2 * 64 + 1));
             xbuf ^= 1; // the next round writes the other buffer: no second barrier needed
             rounds++;
         }
@@ -334,7 +348,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             const bool c1 = alm_iter > 0 && dyn_plus <= c * kp.delta_tol + SMALL;
             const bool c2 = n2 == 0 || f2n_plus <= kp.delta_tol + SMALL;
             const bool c3 = akkt_tol <= kp.tol + SMALL;
-            bool finished = false, converged = false;
+            bool finished = false, converged = false, out_of_time = false;
             if (c1 && c2 && c3) {
                 finished = converged = true;
             } else {
@@ -352,9 +366,13 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 yw = ypw;
                 reset_cache();
                 if (outer >= kp.max_outer) finished = true;
+                else if (!cont_time) {
+                    finished = true;
+                    out_of_time = true;
+                }
             }
             if (finished) {
-                if (!converged) status = 1;
+                if (!converged) status = out_of_time ? 2 : 1;
                 bool finite = tfinite(uv) && tfinite(uw) && tfinite(f_u);
                 if (__ballot(!finite) != 0ull) status = 3;
                 if (wave == 0) {
@@ -404,11 +422,12 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         NMPC_STAMP(I, 10); // phase code (mostly: replaying the line-search tests on the exchanged candidates)
         if (step_done) {
             iteration++;
-            if (!cont) {
+            if (!cont || !cont_time) {
                 step_head = false;
             } else {
                 num_iter++;
                 cont = num_iter < kp.max_inner;
+                if (kp.time_budget > 0) cont_time = (long long)t_now <= kp.time_budget;
                 step_head = true;
             }
         }
@@ -425,7 +444,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             T ff, aa;
             I.dot2x2(fv, fw, fv, fw, a1, a2, a1, a2, ff, aa);
             norm_fpr = tsqrt(ff);
-            const T akkt = tsqrt(aa);
+            const T akkt = kp.akkt_form ? tsqrt(aa) * inv_gamma : tsqrt(aa); // (nmpc_config.akkt_form)
             if (norm_fpr < kp.tol && akkt < akkt_tol) {
                 inner_exit = true;
             } else {
@@ -441,7 +460,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         }
         NMPC_STAMP(I, 11); // step head
         if (inner_exit) {
-            status = cont ? 0 : 1;
+            status = !cont ? 1 : !cont_time ? 2 : 0;
             inner_total += num_iter;
             uv = hv;
             uw = hw;

@@ -35,7 +35,8 @@ class _Options(C.Structure):
                 ("initial_penalty", C.c_double), ("penalty_update", C.c_double),
                 ("inner_tol_update", C.c_double), ("sufficient_decrease", C.c_double),
                 ("lip_delta", C.c_double), ("lip_eps", C.c_double),
-                ("cbfgs_alpha", C.c_double), ("cbfgs_eps", C.c_double), ("sy_eps", C.c_double)]
+                ("cbfgs_alpha", C.c_double), ("cbfgs_eps", C.c_double), ("sy_eps", C.c_double),
+                ("akkt_form", C.c_int32), ("pad_", C.c_int32)]
 
 
 class _Result(C.Structure):
@@ -126,13 +127,14 @@ class Options:
     cbfgs_alpha: float = 1.0
     cbfgs_eps: float = 1e-8
     sy_eps: float = 1e-10
+    akkt_form: int = 0   # 0 = OpEn source form of the AKKT residual, 1 = documented form (see nmpc_oracle.h)
     extra: dict = field(default_factory=dict)
 
     def c(self) -> _Options:
         return _Options(self.tolerance, self.initial_tolerance, self.delta_tolerance, self.max_outer,
                         self.max_inner, self.lbfgs_mem, self.initial_penalty, self.penalty_update,
                         self.inner_tol_update, self.sufficient_decrease, self.lip_delta, self.lip_eps,
-                        self.cbfgs_alpha, self.cbfgs_eps, self.sy_eps)
+                        self.cbfgs_alpha, self.cbfgs_eps, self.sy_eps, self.akkt_form, 0)
 
 
 def _suffix(dtype) -> str:

@@ -34,6 +34,8 @@ void orc_default_options(orc_options *o)
     o->cbfgs_alpha = 1.0;
     o->cbfgs_eps = 1e-8;
     o->sy_eps = 1e-10;
+    o->akkt_form = 0;
+    o->pad_ = 0;
 }
 
 /* ---------------- double ---------------- */

@@ -62,6 +62,10 @@ typedef struct {
     double cbfgs_alpha;          /* 1.0  */
     double cbfgs_eps;            /* 1e-8 */
     double sy_eps;               /* 1e-10 */
+    int32_t akkt_form;           /* AKKT residual of the inner exit test: 0 = OpEn source form (recalled)
+                                    ||gamma*fpr + gamma*(df - df_prev)||, 1 = OpEn documentation ||fpr + df - df_prev||
+                                    (= the former / gamma). See DESIGN.md "AKKT residual". */
+    int32_t pad_;
 } orc_options;
 
 typedef struct {

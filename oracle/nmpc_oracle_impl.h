@@ -535,7 +535,11 @@ static int SUF(panoc_step)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u)
     /* compute_fpr */
     for (int i = 0; i < n; ++i) pc->gfpr[i] = u[i] - pc->u_half[i];
     pc->norm_gfpr = SUF(norm2)(pc->gfpr, n);
-    /* exit_condition: ||gamma*fpr|| < tol  &&  ||gamma*fpr + gamma*(df - df_prev)|| < akkt_tol */
+    /* exit_condition: ||gamma*fpr|| < tol  &&  AKKT residual < akkt_tol.
+     * OpEn: PANOCCache::akkt_residual -- source (recalled): sum (gamma_fpr_i + gamma*(df_i - dfp_i))^2, its doc comment:
+     * ||gamma^{-1}(u - u_plus) + df(u) - df(u_plus)||. The two differ by the factor gamma; op->akkt_form selects.
+     * Note: cache_previous_gradient() has just copied df into df_prev (iteration >= 1), so the gradient difference is
+     * zero after the first iteration and the source form reduces to ||gamma*fpr||. */
     {
         REAL r = 0;
         for (int i = 0; i < n; ++i) {
@@ -543,6 +547,7 @@ static int SUF(panoc_step)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u)
             r += t * t;
         }
         r = SUF(rsqrt)(r);
+        if (cx->op->akkt_form) r /= pc->gamma; /* documented form */
         if (pc->norm_gfpr < pc->tol && r < pc->akkt_tol) return 0;
     }
     /* update_lipschitz_constant */

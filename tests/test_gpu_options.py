@@ -1,0 +1,74 @@
+"""GPU tests of the solver options that round 2 added to the C ABI: the two forms of the AKKT residual
+(nmpc_config.akkt_form, SURVEY.md 8a row A10 / ADVICE r1) and the wall-clock budget (yaml max_solver_time ->
+nmpc_config.max_solver_time_us, NotConvergedOutOfTime)."""
+import numpy as np
+import pytest
+
+import dyobav_mpcnwta_warehouse_amd as nm
+import oracle
+import conftest
+from conftest import config_for
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, scope="module", params=[1, 4], ids=["throughput-kernel", "latency-kernel"])
+def kernel_mode(request):
+    conftest.KERNEL_MODE["latency_waves"] = request.param
+    yield request.param
+    conftest.KERNEL_MODE["latency_waves"] = 0
+
+
+@pytest.mark.parametrize("akkt_form", [0, 1])
+def test_akkt_residual_forms_follow_the_oracle(akkt_form):
+    """Both definitions of the AKKT residual: ||gamma*fpr + gamma*(df - df_prev)|| (OpEn's source as recalled,
+    form 0) and ||fpr + df - df_prev|| (SURVEY row A10 / OpEn's documentation, form 1). Same inner iteration counts
+    and statuses as the oracle run with the same form, f64, equal Lipschitz-estimator step; the two forms must
+    actually differ (form 1 is stricter by 1/gamma: more inner iterations)."""
+    L = nm.scenarios.ParamLayout()
+    P = nm.scenarios.make_batch(48, L, seed=31, n_ped=0, n_boxes=0)
+    pr = oracle.Problem()
+    op = oracle.Options(lip_delta=1e-4, lip_eps=1e-4, akkt_form=akkt_form, max_outer=3)
+    Uo, ro = oracle.solve_batch(pr, op, P, nthreads=8)
+    with nm.Handle(config_for(pr, lip_delta_f64=1e-4, lip_eps_f64=1e-4, akkt_form=akkt_form,
+                              max_outer_iterations=3)) as h:
+        r = h.solve(P)
+    same = r["iters"][:, 1] == ro["inner_iters"]
+    assert same.mean() >= 0.9, same.mean()
+    assert np.mean(r["status"] == ro["status"]) >= 0.95
+    du = np.abs(r["U"] - Uo).max(axis=1)
+    assert np.median(du) < 1e-8 and np.mean(du < 1e-4) >= 0.9
+    # the option is live: the other form takes a different number of inner iterations
+    other = oracle.solve_batch(pr, oracle.Options(lip_delta=1e-4, lip_eps=1e-4, akkt_form=1 - akkt_form, max_outer=3),
+                               P, nthreads=8)[1]
+    hi, lo = (ro, other) if akkt_form == 1 else (other, ro)
+    assert hi["inner_iters"].sum() > 1.5 * lo["inner_iters"].sum()
+
+
+def test_akkt_form_is_validated():
+    cfg = config_for(oracle.Problem(), akkt_form=2)
+    with pytest.raises(nm.NmpcError):
+        nm.Handle(cfg)
+
+
+def test_max_solver_time_budget_yields_out_of_time():
+    """yaml max_solver_time (mpc_builder.py:189): with a budget far below what the solves need, unfinished
+    instances report NotConvergedOutOfTime (status 2, trajectory_tracker.py:334-335 via bad_exit_codes) and stop early;
+    with a generous budget the results are those of the unbudgeted run bit for bit."""
+    L = nm.scenarios.ParamLayout()
+    P = nm.scenarios.make_batch(64, L, seed=32)           # pedestrians walking at the robot: long solves
+    pr = oracle.Problem()
+    with nm.Handle(config_for(pr)) as h:
+        ref = h.solve(P)
+    with nm.Handle(config_for(pr, max_solver_time_us=200.0)) as h:      # 0.2 ms per solve
+        short = h.solve(P)
+    with nm.Handle(config_for(pr, max_solver_time_us=60e6)) as h:       # one minute
+        long_ = h.solve(P)
+    assert np.array_equal(long_["U"], ref["U"]) and np.array_equal(long_["status"], ref["status"])
+    assert np.array_equal(long_["iters"], ref["iters"])
+    slow = ref["iters"][:, 1] > 300                                      # instances that cannot finish in 0.2 ms
+    assert slow.sum() >= 10
+    assert (short["status"][slow] == 2).all(), np.unique(short["status"][slow], return_counts=True)
+    assert (short["iters"][slow, 1] < ref["iters"][slow, 1]).all()
+    assert np.isfinite(short["U"]).all()
+    assert set(np.unique(short["status"])) <= {0, 1, 2}
