@@ -79,8 +79,10 @@ bool is_device_ptr(const void* ptr)
 struct Layout {
     int np, off_rs, off_rv, off_c0, off_c, off_os, off_od, off_qstc, off_qdyn;
     int lds_alpha, lds_poly, lds_seg, lds_seginv, lds_fl0, lds_fl, lds_iflag, lds_hist, lds_rho, lds_total;
-    int lds_xch, lds_total_spec; // latency mode: exchange area appended behind lds_total
+    int lds_xch, lds_total_spec; // latency mode: exchange area + the other wavefronts' parking areas behind lds_total
+    int lds_park;
     int dyn_cap;          // obstacle rows provisioned per instance
+    int rs;               // > 0: register-resident obstacle table with this many slots per lane (LDS keeps t = 0 only)
     bool glb;             // obstacle table streamed from a global workspace instead of LDS
     long long ws_stride;  // workspace elements per instance (glb only)
 };
@@ -92,6 +94,8 @@ constexpr int kSpecWaves = 4; // wavefronts per instance in latency mode (nmpc_s
 constexpr size_t kLdsLimit = 160 * 1024; // bytes of LDS one workgroup may use on gfx950
 
 int round4(int x) { return (x + 3) & ~3; }
+
+constexpr int kRegSlotsSmall = 4, kRegSlotsLarge = 14; // compiled register-table sizes (rows = 3 x slots)
 
 Layout make_layout(const nmpc_config& c, size_t elem_size)
 {
@@ -107,7 +111,14 @@ Layout make_layout(const nmpc_config& c, size_t elem_size)
     L.off_qdyn = L.off_qstc + N;
     L.np = L.off_qdyn + N;
     const int cap = c.max_active_dynobs > 0 && c.max_active_dynobs < c.Ndynobs ? c.max_active_dynobs : c.Ndynobs;
-    const int ne = cap * (N + 1); // rows provisioned in LDS / the workspace
+    // fp32, three lanes per horizon step: the table entries of t >= 1 live in the registers of the one lane that reads
+    // them (nmpc_device.h, RS > 0) when the provisioned rows fit 3 x 4 or 3 x 14
+    L.rs = 0;
+    if (elem_size == 4 && c.reg_table >= 0 && N <= 21 && 64 / N >= 3 && cap > 0) {
+        if (cap <= 3 * kRegSlotsSmall) L.rs = kRegSlotsSmall;
+        else if (cap <= 3 * kRegSlotsLarge) L.rs = kRegSlotsLarge;
+    }
+    const int ne = cap * (L.rs ? 1 : N + 1); // table entries provisioned in LDS / the workspace
     L.dyn_cap = cap;
     L.glb = false;
     L.ws_stride = 0;
@@ -121,8 +132,10 @@ Layout make_layout(const nmpc_config& c, size_t elem_size)
     L.lds_iflag = L.lds_fl + round4(c.Nother);         // int list: robots with a non-zero predicted position
     L.lds_hist = L.lds_iflag + round4(c.Ndynobs);  // int flags / compaction map (an int fits in a T)
     L.lds_rho = L.lds_hist + 4 * nmpc::kMem * N;    // L-BFGS ring: kMem x N x (s_v, s_w, y_v, y_w)
-    L.lds_total = L.lds_rho + round4(2 * nmpc::kMem); // rho[kMem], alpha[kMem]
-    L.lds_xch = L.lds_total;                           // 2 buffers x kSpecWaves x (64 lanes x 2 gradient entries + psi)
+    L.lds_park = L.lds_rho + round4(2 * nmpc::kMem);   // rho[kMem], alpha[kMem]; then the parking area(s) (16-B aligned)
+    const int park_one = nmpc::kParkQuads * 4 * 64;    // elements per wavefront
+    L.lds_total = L.lds_park + park_one;
+    L.lds_xch = L.lds_park;                            // latency kernel (no parking): 2 buffers x kSpecWaves x (64 lanes x 2 gradient entries + psi)
     L.lds_total_spec = L.lds_xch + 2 * kSpecWaves * (2 * 64 + 4);
     if (L.glb || (size_t)L.lds_total * elem_size <= kLdsLimit) break;
     L.glb = true; // second attempt: everything but the ellipse table in LDS
@@ -155,32 +168,38 @@ namespace {
 
 // second launch-bound argument = minimum waves per SIMD; it caps the register allocation (512 / waves)
 #ifndef NMPC_WPE_F32
-#define NMPC_WPE_F32 3
+#define NMPC_WPE_F32 4 // throughput kernel, table in LDS / global memory: fits 128 VGPRs without spilling
 #endif
 #ifndef NMPC_WPE_F64
 #define NMPC_WPE_F64 2
 #endif
-template <typename T, int LPS, bool GLB>
-__global__ __launch_bounds__(64, (sizeof(T) == 4 ? NMPC_WPE_F32 : NMPC_WPE_F64)) void solve_kernel(nmpc::KParams<T> kp)
+// waves per SIMD a kernel variant is compiled for: the large register table needs the 256-register budget
+template <typename T, int RS>
+constexpr int wpe(int f32_default)
+{
+    return sizeof(T) == 8 ? NMPC_WPE_F64 : RS >= kRegSlotsLarge ? 2 : RS > 0 ? 3 : f32_default;
+}
+template <typename T, int LPS, bool GLB, int RS = 0>
+__global__ __launch_bounds__(64, (wpe<T, RS>(NMPC_WPE_F32))) void solve_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    nmpc::solve_instance<T, LPS, GLB>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
+    nmpc::solve_instance<T, LPS, GLB, RS>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
 }
 
 // latency mode: kSpecWaves wavefronts per instance, speculative line search (nmpc_spec.h)
-template <typename T, int LPS, bool GLB>
-__global__ __launch_bounds__(64 * kSpecWaves, (sizeof(T) == 4 ? NMPC_SPEC_WPE_F32 : NMPC_WPE_F64)) void solve_spec_kernel(nmpc::KParams<T> kp)
+template <typename T, int LPS, bool GLB, int RS = 0>
+__global__ __launch_bounds__(64 * kSpecWaves, (wpe<T, RS>(NMPC_SPEC_WPE_F32))) void solve_spec_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    nmpc::solve_instance_spec<T, LPS, GLB>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
+    nmpc::solve_instance_spec<T, LPS, GLB, RS>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
 }
 
-template <typename T, int LPS, bool GLB>
+template <typename T, int LPS, bool GLB, int RS = 0>
 __global__ __launch_bounds__(64) void eval_kernel(nmpc::KParams<T> kp, nmpc::EvalParams<T> ep)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int inst = blockIdx.x, N = kp.N;
-    nmpc::Instance<T, LPS, GLB> I(kp, kp.P + (size_t)inst * kp.np, reinterpret_cast<T*>(smem),
+    nmpc::Instance<T, LPS, GLB, RS> I(kp, kp.P + (size_t)inst * kp.np, reinterpret_cast<T*>(smem),
                                   GLB ? kp.ws + (long long)inst * kp.ws_stride : nullptr);
     if (!I.load()) {
         if (I.lane == 0) ep.psi[inst] = __builtin_nanf("");
@@ -272,6 +291,7 @@ void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k)
     k.lds_rho = L.lds_rho;
     k.lds_total = L.lds_total;
     k.lds_xch = L.lds_xch;
+    k.lds_park = L.lds_park;
     k.ts = (T)c.ts;
     k.inv_ts = (T)(1.0 / c.ts);
     k.vmin = (T)c.lin_vel_min;
@@ -308,22 +328,35 @@ using SolveFn = void (*)(nmpc::KParams<T>);
 template <typename T>
 using EvalFn = void (*)(nmpc::KParams<T>, nmpc::EvalParams<T>);
 
+// the register-table variants exist for float with three lanes per step only
 template <typename T>
-SolveFn<T> pick_solve(int lps, bool glb)
+SolveFn<T> pick_solve(int lps, bool glb, int rs = 0)
 {
+    if constexpr (sizeof(T) == 4) {
+        if (rs == kRegSlotsSmall && lps == 3 && !glb) return solve_kernel<T, 3, false, kRegSlotsSmall>;
+        if (rs == kRegSlotsLarge && lps == 3 && !glb) return solve_kernel<T, 3, false, kRegSlotsLarge>;
+    }
     if (glb) return lps == 3 ? solve_kernel<T, 3, true> : lps == 2 ? solve_kernel<T, 2, true> : solve_kernel<T, 1, true>;
     return lps == 3 ? solve_kernel<T, 3, false> : lps == 2 ? solve_kernel<T, 2, false> : solve_kernel<T, 1, false>;
 }
 template <typename T>
-SolveFn<T> pick_solve_spec(int lps, bool glb)
+SolveFn<T> pick_solve_spec(int lps, bool glb, int rs = 0)
 {
+    if constexpr (sizeof(T) == 4) {
+        if (rs == kRegSlotsSmall && lps == 3 && !glb) return solve_spec_kernel<T, 3, false, kRegSlotsSmall>;
+        if (rs == kRegSlotsLarge && lps == 3 && !glb) return solve_spec_kernel<T, 3, false, kRegSlotsLarge>;
+    }
     if (glb) return lps == 3 ? solve_spec_kernel<T, 3, true> : lps == 2 ? solve_spec_kernel<T, 2, true> : solve_spec_kernel<T, 1, true>;
     return lps == 3 ? solve_spec_kernel<T, 3, false> : lps == 2 ? solve_spec_kernel<T, 2, false> : solve_spec_kernel<T, 1, false>;
 }
 
 template <typename T>
-EvalFn<T> pick_eval(int lps, bool glb)
+EvalFn<T> pick_eval(int lps, bool glb, int rs = 0)
 {
+    if constexpr (sizeof(T) == 4) {
+        if (rs == kRegSlotsSmall && lps == 3 && !glb) return eval_kernel<T, 3, false, kRegSlotsSmall>;
+        if (rs == kRegSlotsLarge && lps == 3 && !glb) return eval_kernel<T, 3, false, kRegSlotsLarge>;
+    }
     if (glb) return lps == 3 ? eval_kernel<T, 3, true> : lps == 2 ? eval_kernel<T, 2, true> : eval_kernel<T, 1, true>;
     return lps == 3 ? eval_kernel<T, 3, false> : lps == 2 ? eval_kernel<T, 2, false> : eval_kernel<T, 1, false>;
 }
@@ -413,7 +446,7 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
         // Obstacle table streamed from the global workspace (GLB): the wavefronts of a workgroup read the same
         // 236 KB at about the same time, so speculation rides on cache hits (configs[4]: 1.31 k -> 1.58 k solves/s)
         if (L.glb) lw = kSpecWaves;
-        const int max_waves = (sizeof(T) == 4 ? 3 : 2) * 4; // per CU, from the VGPR budget of the kernels
+        const int max_waves = (sizeof(T) == 4 && L.rs < kRegSlotsLarge ? 3 : 2) * 4; // per CU, from the VGPR budget of the kernels
         const size_t elem = sizeof(T);
         const int tp = std::min<int>(max_waves, (int)(kLdsLimit / ((size_t)L.lds_total * elem)));
         const int wg_spec = (int)(kLdsLimit / ((size_t)L.lds_total_spec * elem));
@@ -429,7 +462,7 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
     int waves = lw == 1 ? 0 : lw < 0 ? 1 : lw > kSpecWaves ? kSpecWaves : lw;
     if (!h->spec_ok[sizeof(T) == 4 ? 0 : 1]) waves = 0;
     const size_t lds_bytes = (size_t)(waves ? L.lds_total_spec : L.lds_total) * sizeof(T);
-    SolveFn<T> fn = waves ? pick_solve_spec<T>(h->lps, L.glb) : pick_solve<T>(h->lps, L.glb);
+    SolveFn<T> fn = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs) : pick_solve<T>(h->lps, L.glb, L.rs);
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(fn, dim3(B), dim3(waves ? 64 * waves : 64), lds_bytes, h->stream, k);
     HIP_TRY(hipGetLastError());
@@ -479,7 +512,7 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
     if ((rc = stage_out(h->dgrad, grad, (size_t)B * n, &ep.grad, &hgrad))) return rc;
     if ((rc = stage_out(h->df2, f2sq, (size_t)B, &ep.f2sq, &hf2))) return rc;
     const size_t lds_bytes = (size_t)L.lds_total * sizeof(T);
-    EvalFn<T> fn = pick_eval<T>(h->lps, L.glb);
+    EvalFn<T> fn = pick_eval<T>(h->lps, L.glb, L.rs);
     hipLaunchKernelGGL(fn, dim3(B), dim3(64), lds_bytes, h->stream, k, ep);
     HIP_TRY(hipGetLastError());
     if (hpsi) HIP_TRY(hipMemcpyAsync(psi, ep.psi, (size_t)B * sizeof(T), hipMemcpyDeviceToHost, h->stream));
@@ -592,16 +625,16 @@ int set_lds_limit(nmpc_handle_s* h)
     const Layout& L = h->lay<T>();
     const size_t lds_bytes = (size_t)L.lds_total * sizeof(T);
     if (lds_bytes > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve<T>(h->lps, L.glb)),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve<T>(h->lps, L.glb, L.rs)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_eval<T>(h->lps, L.glb)),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_eval<T>(h->lps, L.glb, L.rs)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
     const size_t spec_bytes = (size_t)L.lds_total_spec * sizeof(T);
     if (spec_bytes > kLdsLimit) {
         h->spec_ok[sizeof(T) == 4 ? 0 : 1] = false; // no room for the exchange area: latency mode unavailable
     } else if (spec_bytes > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve_spec<T>(h->lps, L.glb)),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve_spec<T>(h->lps, L.glb, L.rs)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)spec_bytes));
     }
     return 0;
@@ -657,6 +690,7 @@ int nmpc_default_config(nmpc_config* c)
     c->max_solver_time_us = 0.0;
     c->coop_waves = 0;
     c->lbfgs_gram = 0;
+    c->reg_table = 0;
     return 0;
 }
 
@@ -683,8 +717,7 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "akkt_form = %d (0 = OpEn source form, 1 = documented form)", cfg->akkt_form);
     if (!(cfg->max_solver_time_us >= 0))
         return fail(NMPC_ERR_INVALID_ARGUMENT, "max_solver_time_us < 0");
-    for (int r : cfg->reserved)
-        if (r != 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "reserved fields must be 0");
+    if (cfg->reserved0 != 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "reserved fields must be 0");
     if (!(cfg->ts > 0) || cfg->max_outer_iterations < 1 || cfg->max_inner_iterations < 1 ||
         !(cfg->initial_penalty > 0))
         return fail(NMPC_ERR_INVALID_ARGUMENT, "bad ts / iteration caps / initial penalty");
@@ -839,13 +872,13 @@ int nmpc_kernel_info(nmpc_handle h, int32_t* lds_bytes_f32, int32_t* lds_bytes_f
     if (waves_per_cu_f32) {
         int nb = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &nb, reinterpret_cast<const void*>(pick_solve<float>(h->lps, h->lay32.glb)), 64, l32));
+            &nb, reinterpret_cast<const void*>(pick_solve<float>(h->lps, h->lay32.glb, h->lay32.rs)), 64, l32));
         *waves_per_cu_f32 = nb;
     }
     if (waves_per_cu_f64) {
         int nb = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &nb, reinterpret_cast<const void*>(pick_solve<double>(h->lps, h->lay64.glb)), 64, l64));
+            &nb, reinterpret_cast<const void*>(pick_solve<double>(h->lps, h->lay64.glb, h->lay64.rs)), 64, l64));
         *waves_per_cu_f64 = nb;
     }
     return 0;

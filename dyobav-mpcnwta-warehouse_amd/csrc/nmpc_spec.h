@@ -28,7 +28,7 @@ namespace nmpc {
 
 enum SpecPhase : int { SP_INIT_A, SP_INIT_B, SP_LIP, SP_SPEC0, SP_NOLS, SP_LSN, SP_OUTER };
 
-template <typename T, int LPS, bool GLB>
+template <typename T, int LPS, bool GLB, int RS = 0>
 __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const int inst, T* lds)
 {
     // W is a run-time value (workgroup size / 64, at most kMaxSpecWaves) so that every choice of W executes the very
@@ -39,44 +39,50 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     const int MAX_LIP = 10, MAX_LS = 10;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 
-    Instance<T, LPS, GLB> I(kp, kp.P + (size_t)inst * kp.np, lds, GLB ? kp.ws + (long long)inst * kp.ws_stride : nullptr);
+    Instance<T, LPS, GLB, RS> I(kp, kp.P + (size_t)inst * kp.np, lds, GLB ? kp.ws + (long long)inst * kp.ws_stride : nullptr);
     if (!I.load()) { // NMPC_CAPACITY_EXCEEDED (uniform over the workgroup)
         const T nan = __builtin_nanf("");
+        const auto* kc = cold_args<T>();
         if (wave == 0) {
             if (I.lead) {
-                kp.U[(size_t)inst * 2 * kp.N + 2 * I.k] = nan;
-                kp.U[(size_t)inst * 2 * kp.N + 2 * I.k + 1] = nan;
+                kc->U[(size_t)inst * 2 * kp.N + 2 * I.k] = nan;
+                kc->U[(size_t)inst * 2 * kp.N + 2 * I.k + 1] = nan;
             }
             if (I.lane == 0) {
-                if (kp.cost) kp.cost[inst] = nan;
-                if (kp.status) kp.status[inst] = 4;
-                if (kp.iters) kp.iters[2 * inst] = kp.iters[2 * inst + 1] = 0;
-                if (kp.info)
-                    for (int i = 0; i < 8 + kProfSlots; ++i) kp.info[(size_t)inst * (8 + kProfSlots) + i] = 0;
+                if (kc->cost) kc->cost[inst] = nan;
+                if (kc->status) kc->status[inst] = 4;
+                if (kc->iters) kc->iters[2 * inst] = kc->iters[2 * inst + 1] = 0;
+                if (kc->info)
+                    for (int i = 0; i < 8 + kProfSlots; ++i) kc->info[(size_t)inst * (8 + kProfSlots) + i] = 0;
             }
         }
         return;
     }
     const int N = kp.N, n2 = kp.Ndyn;
+    const int mem = kp.mem;
     const int kk = I.act ? I.k : 0;
     const bool lead = I.lead;
 
     T uv = 0, uw = 0, yv = 0, yw = 0;
-    if (kp.u0) {
-        uv = kp.u0[(size_t)inst * 2 * N + 2 * kk];
-        uw = kp.u0[(size_t)inst * 2 * N + 2 * kk + 1];
-    }
-    if (kp.y && kp.y_is_input) {
-        yv = kp.y[(size_t)inst * 2 * N + kk];
-        yw = kp.y[(size_t)inst * 2 * N + N + kk];
+    T c;
+    {
+        const auto* kc = cold_args<T>();
+        if (kc->u0) {
+            uv = kc->u0[(size_t)inst * 2 * N + 2 * kk];
+            uw = kc->u0[(size_t)inst * 2 * N + 2 * kk + 1];
+        }
+        if (kc->y && kc->y_is_input) {
+            yv = kc->y[(size_t)inst * 2 * N + kk];
+            yw = kc->y[(size_t)inst * 2 * N + N + kk];
+        }
+        c = kc->c0v ? kc->c0v[inst] : kc->c_init;
     }
     if (!I.act) uv = uw = yv = yw = 0;
-    T c = kp.c0v ? kp.c0v[inst] : kp.c_init;
 
     // PANOC cache (same names as solve_instance)
     T gv = 0, gw = 0, gpv = 0, gpw = 0, hv = 0, hw = 0, sv = 0, sw = 0, dv = 0, dw = 0, fv = 0, fw = 0, pv = 0, pw = 0;
     T gamma = 0, inv_gamma = 0, L = 0, sigma = 0, tau = 1, cost_value = 0, norm_fpr = 0, rhs_ls = 0;
-    T akkt_tol = kp.init_tol;
+    T akkt_tol = cold_args<T>()->init_tol;
     int iteration = 0;
     Quad<T>* hist = reinterpret_cast<Quad<T>*>(lds + kp.lds_hist);
     LaneVec<T> rho; // rho_i by physical slot (every wavefront keeps its own, identical copy)
@@ -92,7 +98,8 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     int alg_psi = 0, alg_grad = 0, rounds = 0; // evaluations the sequential algorithm performs / exchange rounds
     // max_solver_time: wavefront 0 publishes its elapsed real-time ticks with every exchange round, so that all
     // wavefronts of the workgroup take the same decision (see solve_instance)
-    const long long t_start = kp.time_budget > 0 ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+    const long long time_budget = cold_args<T>()->time_budget;
+    const long long t_start = time_budget > 0 ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
     int t_now = 0;
     bool cont_time = true;
 
@@ -205,13 +212,13 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 }
                 if (I.lane == 0) xw[2 * 64] = r_psi;
             }
-            if (kp.time_budget > 0 && wave == 0 && I.lane == 0) {
+            if (time_budget > 0 && wave == 0 && I.lane == 0) {
                 long long el = (long long)__builtin_amdgcn_s_memrealtime() - t_start;
                 if (el > 0x7fffffffll) el = 0x7fffffffll;
                 *reinterpret_cast<int*>(xw + 2 * 64 + 1) = (int)el;
             }
             __syncthreads();
-            if (kp.time_budget > 0)
+            if (time_budget > 0)
                 t_now = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(xr + 2 * 64 + 1));
             xbuf ^= 1; // the next round writes the other buffer: no second barrier needed
             rounds++;
@@ -256,8 +263,10 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             cost_value = r_psi;
             gv = r_gv;
             gw = r_gw;
-            const T e1 = kp.lip_eps * uv, e2 = kp.lip_eps * uw;
-            const T h1 = e1 > kp.lip_delta ? e1 : kp.lip_delta, h2 = e2 > kp.lip_delta ? e2 : kp.lip_delta;
+            const auto* kc = cold_args<T>();
+            const T lip_eps = kc->lip_eps, lip_delta = kc->lip_delta;
+            const T e1 = lip_eps * uv, e2 = lip_eps * uw;
+            const T h1 = e1 > lip_delta ? e1 : lip_delta, h2 = e2 > lip_delta ? e2 : lip_delta;
             normh = tsqrt(I.dot2(h1, h2, h1, h2));
             if (I.act) {
                 uv += h1;
@@ -332,40 +341,41 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             }
         } else { // SP_OUTER
             alg_psi++;
+            const auto* kc = cold_args<T>();
             const T f_u = r_psi;
             f2n_plus = tsqrt(r_f2);
             const T v_up = wave_shift_up<LPS>(uv), w_up = wave_shift_up<LPS>(uw);
-            const T vprev = I.k == 0 ? I.vinit : v_up;
-            const T wprev = I.k == 0 ? I.winit : w_up;
-            const T acc = (uv - vprev) * kp.inv_ts, wacc = (uw - wprev) * kp.inv_ts;
+            const T vprev = I.k == 0 ? I.p[0] : v_up;
+            const T wprev = I.k == 0 ? I.p[1] : w_up;
+            const T acc = (uv - vprev) * kc->inv_ts, wacc = (uw - wprev) * kc->inv_ts;
             const T za = acc + yv / c, zw = wacc + yw / c;
-            T ypv = yv + c * (acc - tclamp(za, kp.amin, kp.amax));
-            T ypw = yw + c * (wacc - tclamp(zw, -kp.wamax, kp.wamax));
+            T ypv = yv + c * (acc - tclamp(za, kc->amin, kc->amax));
+            T ypw = yw + c * (wacc - tclamp(zw, -kc->wamax, kc->wamax));
             if (!I.act) ypv = ypw = 0;
             const T e1 = ypv - yv, e2 = ypw - yw;
             dyn_plus = tsqrt(I.dot2(e1, e2, e1, e2));
             const T SMALL = Lim<T>::eps;
-            const bool c1 = alm_iter > 0 && dyn_plus <= c * kp.delta_tol + SMALL;
-            const bool c2 = n2 == 0 || f2n_plus <= kp.delta_tol + SMALL;
-            const bool c3 = akkt_tol <= kp.tol + SMALL;
+            const bool c1 = alm_iter > 0 && dyn_plus <= c * kc->delta_tol + SMALL;
+            const bool c2 = n2 == 0 || f2n_plus <= kc->delta_tol + SMALL;
+            const bool c3 = akkt_tol <= kc->tol + SMALL;
             bool finished = false, converged = false, out_of_time = false;
             if (c1 && c2 && c3) {
                 finished = converged = true;
             } else {
-                const bool stall = alm_iter == 0 || ((dyn_plus <= kp.suff_dec * dyn + SMALL) &&
-                                                     (n2 == 0 || f2n_plus <= kp.suff_dec * f2n + SMALL));
+                const bool stall = alm_iter == 0 || ((dyn_plus <= kc->suff_dec * dyn + SMALL) &&
+                                                     (n2 == 0 || f2n_plus <= kc->suff_dec * f2n + SMALL));
                 if (!stall) {
-                    c *= kp.pen_update;
+                    c *= kc->pen_update;
                     inv_cdiv = T(1) / (c > T(1) ? c : T(1));
                 }
-                akkt_tol = tmax(akkt_tol * kp.tol_update, kp.tol);
+                akkt_tol = tmax(akkt_tol * kc->tol_update, kc->tol);
                 alm_iter++;
                 dyn = dyn_plus;
                 f2n = f2n_plus;
                 yv = ypv;
                 yw = ypw;
                 reset_cache();
-                if (outer >= kp.max_outer) finished = true;
+                if (outer >= kc->max_outer) finished = true;
                 else if (!cont_time) {
                     finished = true;
                     out_of_time = true;
@@ -377,22 +387,22 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 if (__ballot(!finite) != 0ull) status = 3;
                 if (wave == 0) {
                     if (lead) {
-                        kp.U[(size_t)inst * 2 * N + 2 * I.k] = uv;
-                        kp.U[(size_t)inst * 2 * N + 2 * I.k + 1] = uw;
-                        if (kp.y) {
-                            kp.y[(size_t)inst * 2 * N + I.k] = yv;
-                            kp.y[(size_t)inst * 2 * N + N + I.k] = yw;
+                        kc->U[(size_t)inst * 2 * N + 2 * I.k] = uv;
+                        kc->U[(size_t)inst * 2 * N + 2 * I.k + 1] = uw;
+                        if (kc->y) {
+                            kc->y[(size_t)inst * 2 * N + I.k] = yv;
+                            kc->y[(size_t)inst * 2 * N + N + I.k] = yw;
                         }
                     }
                     if (I.lane == 0) {
-                        if (kp.cost) kp.cost[inst] = f_u;
-                        if (kp.status) kp.status[inst] = status;
-                        if (kp.iters) {
-                            kp.iters[2 * inst] = outer;
-                            kp.iters[2 * inst + 1] = inner_total;
+                        if (kc->cost) kc->cost[inst] = f_u;
+                        if (kc->status) kc->status[inst] = status;
+                        if (kc->iters) {
+                            kc->iters[2 * inst] = outer;
+                            kc->iters[2 * inst + 1] = inner_total;
                         }
-                        if (kp.info) {
-                            T* o = kp.info + (size_t)inst * (8 + kProfSlots);
+                        if (kc->info) {
+                            T* o = kc->info + (size_t)inst * (8 + kProfSlots);
                             o[0] = norm_fpr;
                             o[1] = f2n_plus;
                             o[2] = dyn_plus;
@@ -426,8 +436,8 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 step_head = false;
             } else {
                 num_iter++;
-                cont = num_iter < kp.max_inner;
-                if (kp.time_budget > 0) cont_time = (long long)t_now <= kp.time_budget;
+                cont = num_iter < cold_args<T>()->max_inner;
+                if (time_budget > 0) cont_time = (long long)t_now <= time_budget;
                 step_head = true;
             }
         }
@@ -444,8 +454,9 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             T ff, aa;
             I.dot2x2(fv, fw, fv, fw, a1, a2, a1, a2, ff, aa);
             norm_fpr = tsqrt(ff);
-            const T akkt = kp.akkt_form ? tsqrt(aa) * inv_gamma : tsqrt(aa); // (nmpc_config.akkt_form)
-            if (norm_fpr < kp.tol && akkt < akkt_tol) {
+            const auto* kc = cold_args<T>();
+            const T akkt = kc->akkt_form ? tsqrt(aa) * inv_gamma : tsqrt(aa); // (nmpc_config.akkt_form)
+            if (norm_fpr < kc->tol && akkt < akkt_tol) {
                 inner_exit = true;
             } else {
                 lip_it = 0;
@@ -484,11 +495,13 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             T ys, ss;
             I.dot2x2(nsv, nsw, nyv, nyw, nsv, nsw, nsv, nsw, ys, ss);
             bool ok = true;
-            if (ss <= Lim<T>::min_pos || (kp.sy_eps > T(0) && ys <= kp.sy_eps)) {
+            const auto* kc = cold_args<T>();
+            const T sy_eps = kc->sy_eps, cbfgs_eps = kc->cbfgs_eps, cbfgs_alpha = kc->cbfgs_alpha;
+            if (ss <= Lim<T>::min_pos || (sy_eps > T(0) && ys <= sy_eps)) {
                 ok = false;
-            } else if (kp.cbfgs_eps > T(0) && kp.cbfgs_alpha > T(0)) {
+            } else if (cbfgs_eps > T(0) && cbfgs_alpha > T(0)) {
                 const T lhs = ys / ss;
-                const T rhs_c = kp.cbfgs_eps * (kp.cbfgs_alpha == T(1) ? norm_fpr : tpow(norm_fpr, kp.cbfgs_alpha));
+                const T rhs_c = cbfgs_eps * (cbfgs_alpha == T(1) ? norm_fpr : tpow(norm_fpr, cbfgs_alpha));
                 ok = lhs > rhs_c && tfinite(lhs) && tfinite(rhs_c);
             }
             if (ok) {
@@ -496,12 +509,12 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 osw = uw;
                 ogv = fv;
                 ogw = fw;
-                lb_head = lb_head == 0 ? kp.mem - 1 : lb_head - 1;
+                lb_head = lb_head == 0 ? mem - 1 : lb_head - 1;
                 // all wavefronts write the same values to the same addresses
                 if (lead) hist[lb_head * N + I.k] = Quad<T>{nsv, nsw, nyv, nyw};
                 rho.set(lb_head, T(1) / ys);
                 lb_gamma = ys / I.dot2(nyv, nyw, nyv, nyw);
-                lb_active = lb_active + 1 < kp.mem ? lb_active + 1 : kp.mem;
+                lb_active = lb_active + 1 < mem ? lb_active + 1 : mem;
                 __syncthreads();
             }
         }
@@ -513,7 +526,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             phase = SP_NOLS;
             continue;
         }
-        lbfgs_apply(I, hist, rho, N, kk, kp.mem, lb_head, lb_active, lb_gamma, fv, fw, dv, dw);
+        lbfgs_apply(I, hist, rho, N, kk, mem, lb_head, lb_active, lb_gamma, fv, fw, dv, dw);
         NMPC_STAMP(I, 13); // two-loop recursion
         if (!fbe_valid) {
             const T t1 = sv - hv, t2 = sw - hw;

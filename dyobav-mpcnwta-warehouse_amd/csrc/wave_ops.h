@@ -108,6 +108,27 @@ __device__ __forceinline__ void wave_sum3(float x, float y, float z, float& sx, 
     sy = read_lane(y, 63);
     sz = read_lane(z, 63);
 }
+// six independent sums: with six chains in flight no DPP wait state is left to pad
+#define NMPC_P6(ctrl)                                                                                         \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl \
+    "\n\tv_add_f32_dpp %3, %3, %3 " ctrl "\n\tv_add_f32_dpp %4, %4, %4 " ctrl "\n\tv_add_f32_dpp %5, %5, %5 " ctrl "\n\t"
+__device__ __forceinline__ void wave_sum6(float (&x)[6])
+{
+    asm("s_nop 1\n\t" NMPC_P6("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+            NMPC_P6("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                NMPC_P6("row_half_mirror row_mask:0xf bank_mask:0xf") NMPC_P6("row_mirror row_mask:0xf bank_mask:0xf")
+                    NMPC_P6("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                        NMPC_P6("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = read_lane(x[i], 63);
+}
+#undef NMPC_P6
+__device__ __forceinline__ void wave_sum6(double (&x)[6])
+{
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = wave_sum(x[i]);
+}
 __device__ __forceinline__ void wave_sum2(double x, double y, double& sx, double& sy)
 {
     sx = wave_sum(x);

@@ -33,7 +33,7 @@ def test_config_struct_matches_header_defaults():
     assert cfg.tolerance == 1e-4 and cfg.initial_penalty == 10.0 and cfg.max_inner_iterations == 500
     assert cfg.max_outer_iterations == 10 and cfg.lbfgs_memory == 10
     assert cfg.latency_waves == 0 and cfg.akkt_form == 0 and cfg.max_solver_time_us == 0.0
-    assert cfg.coop_waves == 0 and cfg.lbfgs_gram == 0 and list(cfg.reserved) == [0, 0]
+    assert cfg.coop_waves == 0 and cfg.lbfgs_gram == 0 and cfg.reg_table == 0 and cfg.reserved0 == 0
     # struct size and a late field's offset: ctypes mirror vs the C compiler on include/nmpc_hip.h (catches field drift)
     import subprocess, tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

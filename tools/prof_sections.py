@@ -29,3 +29,4 @@ ne = info[:, 4].astype(np.float64).sum(); ng = info[:, 5].astype(np.float64).sum
 print(f"evals {ne:.3e} (grad {ng:.3e}) = {ne/B:.0f} per solve; cycles/eval total {tot/ne:.0f}")
 for i, n in enumerate(names):
     print(f"  {n:40s} {prof[:, i].sum()/tot*100:5.1f}%   {prof[:, i].sum()/ne:8.0f} ticks/eval")
+print(f"ellipse slots visited {prof[:,13].sum():.3e}; any soft term active {prof[:,14].sum()/prof[:,13].sum()*100:.1f}%; any hard term active {prof[:,15].sum()/prof[:,13].sum()*100:.1f}%")
