@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--latency-waves", type=int, default=0,
                     help="nmpc_config.latency_waves: 0 = automatic (library default), 1 = one wavefront per instance, "
                          "4 = latency mode")
+    ap.add_argument("--reg-table", type=int, default=0, help="nmpc_config.reg_table: 0 = automatic, -1 = LDS / global table")
     args = ap.parse_args()
 
     # stdout must carry exactly ONE JSON line: RCCL / HIP libraries print banners and warnings on fd 1, so keep a
@@ -126,6 +127,7 @@ def main():
     # the reference's zero padding (mpc_interface.py:82-88); fewer provisioned rows -> less LDS per instance
     cfg.max_active_dynobs = spec["n_ped"] * spec["n_hyp"]
     cfg.latency_waves = args.latency_waves
+    cfg.reg_table = args.reg_table
     h = nm.Handle(cfg)
     stream = torch.cuda.current_stream()
     h.set_stream(stream.cuda_stream)

@@ -118,7 +118,7 @@ Layout make_layout(const nmpc_config& c, size_t elem_size)
         if (cap <= 3 * kRegSlotsSmall) L.rs = kRegSlotsSmall;
         else if (cap <= 3 * kRegSlotsLarge) L.rs = kRegSlotsLarge;
     }
-    const int ne = cap * (L.rs ? 1 : N + 1); // table entries provisioned in LDS / the workspace
+    const int ne = L.rs ? cap + 1 : cap * (N + 1); // table entries provisioned in LDS / the workspace (register table: t = 0 rows + the dummy)
     L.dyn_cap = cap;
     L.glb = false;
     L.ws_stride = 0;
@@ -135,7 +135,9 @@ Layout make_layout(const nmpc_config& c, size_t elem_size)
     L.lds_park = L.lds_rho + round4(2 * nmpc::kMem);   // rho[kMem], alpha[kMem]; then the parking area(s) (16-B aligned)
     const int park_one = nmpc::kParkQuads * 4 * 64;    // elements per wavefront
     L.lds_total = L.lds_park + park_one;
-    L.lds_xch = L.lds_park;                            // latency kernel (no parking): 2 buffers x kSpecWaves x (64 lanes x 2 gradient entries + psi)
+    // latency kernel: one parking area per wavefront (register-table variants only), then the exchange area:
+    // 2 buffers x kSpecWaves x (64 lanes x 2 gradient entries + psi)
+    L.lds_xch = L.lds_park + (L.rs ? kSpecWaves * park_one : 0);
     L.lds_total_spec = L.lds_xch + 2 * kSpecWaves * (2 * 64 + 4);
     if (L.glb || (size_t)L.lds_total * elem_size <= kLdsLimit) break;
     L.glb = true; // second attempt: everything but the ellipse table in LDS
@@ -437,7 +439,9 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
     // fewer 4-wavefront workgroups are resident
     const int cap = sizeof(T) == 4 ? h->n_simd : h->n_simd / 2;
     if (lw == 0) {
-        lw = B <= cap ? kSpecWaves : B <= 4 * cap ? 2 : 1;
+        // one workgroup per SIMD or less: as many wavefronts per instance as stay resident together (3 per SIMD in
+        // fp32: measured on configs[1], W = 3 28.5 k solves/s against 25.1 k with W = 4 and 25.8 k with W = 2)
+        lw = B <= cap ? (sizeof(T) == 4 ? (L.rs >= kRegSlotsLarge ? 2 : NMPC_SPEC_WPE_F32) : kSpecWaves) : B <= 4 * cap ? 2 : 1;
         // Large batches whose LDS tables allow only a few workgroups per CU (e.g. 40 active obstacle rows: 35 KB,
         // 4 per CU = one wavefront per SIMD): the wavefronts of a latency-kernel workgroup SHARE the instance's
         // tables, so W of them fill the SIMDs that the throughput kernel leaves empty (measured on configs[2]:
@@ -446,13 +450,16 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
         // Obstacle table streamed from the global workspace (GLB): the wavefronts of a workgroup read the same
         // 236 KB at about the same time, so speculation rides on cache hits (configs[4]: 1.31 k -> 1.58 k solves/s)
         if (L.glb) lw = kSpecWaves;
-        const int max_waves = (sizeof(T) == 4 && L.rs < kRegSlotsLarge ? 3 : 2) * 4; // per CU, from the VGPR budget of the kernels
+        // resident wavefronts per CU: register budget of the kernel variant (wpe<>) x 4 SIMDs, capped by LDS
+        const bool f32 = sizeof(T) == 4;
+        const int wpe_tp = !f32 ? NMPC_WPE_F64 : L.rs >= kRegSlotsLarge ? 2 : L.rs > 0 ? 3 : NMPC_WPE_F32;
+        const int wpe_sp = !f32 ? NMPC_WPE_F64 : L.rs >= kRegSlotsLarge ? 2 : NMPC_SPEC_WPE_F32;
         const size_t elem = sizeof(T);
-        const int tp = std::min<int>(max_waves, (int)(kLdsLimit / ((size_t)L.lds_total * elem)));
+        const int tp = std::min<int>(4 * wpe_tp, (int)(kLdsLimit / ((size_t)L.lds_total * elem)));
         const int wg_spec = (int)(kLdsLimit / ((size_t)L.lds_total_spec * elem));
         int best = tp;
         for (int w = std::max(lw, 2); w <= kSpecWaves; ++w) {
-            const int res = std::min(max_waves / w, wg_spec) * w;
+            const int res = std::min(4 * wpe_sp / w, wg_spec) * w;
             if (2 * res >= 3 * tp && res > best) {
                 best = res;
                 lw = w;

@@ -136,6 +136,28 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         fbe_valid = false;
     };
 
+    // cold solver vectors parked in LDS across the evaluation (see solve_instance); one area per wavefront
+    constexpr bool kSpecPark = RS > 0; // (the LDS-table variants fit their register budget without; measured)
+    Quad<T>* const parkp = reinterpret_cast<Quad<T>*>(lds + kp.lds_park) + wave * (kParkQuads * 64) + I.lane;
+    auto park = [&]() {
+        parkp[0 * 64] = Quad<T>{osv, osw, ogv, ogw};
+        parkp[1 * 64] = Quad<T>{gpv, gpw, sv, sw};
+        parkp[2 * 64] = Quad<T>{pv, pw, dv, dw};
+        parkp[3 * 64] = Quad<T>{hv, hw, fv, fw};
+        parkp[4 * 64] = Quad<T>{uv, uw, gv, gw};
+        asm volatile("" ::: "memory");
+    };
+    auto unpark = [&]() {
+        asm volatile("" ::: "memory");
+        const Quad<T> q0 = parkp[0 * 64], q1 = parkp[1 * 64], q2 = parkp[2 * 64], q3 = parkp[3 * 64],
+                      q4 = parkp[4 * 64];
+        osv = q0.a, osw = q0.b, ogv = q0.c, ogw = q0.d;
+        gpv = q1.a, gpw = q1.b, sv = q1.c, sw = q1.d;
+        pv = q2.a, pw = q2.b, dv = q2.c, dw = q2.d;
+        hv = q3.a, hw = q3.b, fv = q3.c, fw = q3.d;
+        uv = q4.a, uw = q4.b, gv = q4.c, gw = q4.d;
+    };
+
     int phase = SP_INIT_A;
     T ev = uv, ew = uw, ec = c;
     T inv_cdiv = T(1) / (c > T(1) ? c : T(1));
@@ -196,10 +218,12 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         fbe_valid = unib(fbe_valid);
         const T e_icd = ec == c ? inv_cdiv : T(1);
         if (do_eval) {
+            if (kSpecPark) park();
             if (want_grad)
                 I.template eval<true>(ev, ew, ec, e_icd, yv, yw, r_psi, r_f2, r_gv, r_gw);
             else
                 I.template eval<false>(ev, ew, ec, e_icd, yv, yw, r_psi, r_f2, r_gv, r_gw);
+            if (kSpecPark) unpark();
         }
         NMPC_STAMP(I, 7); // (eval epilogue)
         const T* xr = xch + xbuf * (W * XS); // results of this round, one row per wavefront
