@@ -104,7 +104,8 @@ def make_batch(B: int, layout: ParamLayout = ParamLayout(), seed: int = 0, n_ped
     (``main_base.py:293-302``); remaining Ndyn slots zero (``interfaces/mpc_interface.py:82-88``).
     ``ped_mode="oncoming"`` (not a BASELINE configuration; used by the parity tests) makes the pedestrians walk
     against the robot's heading +-0.3 rad instead of straight at it, which keeps the hard ellipse constraint
-    feasible for most instances so that the solver converges instead of running into its iteration caps.
+    feasible for more instances; ``ped_mode="passing"`` puts them on a parallel lane 1.5-4 m (x fan width) to the side (hard
+    constraint feasible: the family where the solver converges, reported next to the contract family by bench.py).
     Static: ``n_boxes`` axis-aligned 1 x 2 m boxes within 6 m of the robot; remaining slots zero.
     Other robots: zero (reference default, ``trajectory_tracker.py:295-296``).
     """
@@ -159,6 +160,15 @@ def make_batch(B: int, layout: ParamLayout = ParamLayout(), seed: int = 0, n_ped
             base_ang = np.arctan2(to_robot[..., 1], to_robot[..., 0])
         elif ped_mode == "oncoming":
             base_ang = (th[:, None] + np.pi) + rng.uniform(-0.3, 0.3, size=(B, n_ped))
+        elif ped_mode == "passing":
+            # pedestrians pass on a parallel lane 1.5-4 m (x fan width) to the side, against the robot's heading: the obstacle terms
+            # are exercised (soft margins are touched now and then) while the hard constraint stays feasible -- the
+            # operating point of the reference's warehouse runs, where the solver converges
+            # (offset scaled with the width of the hypothesis fan, (n_hyp - 1) * 0.075 rad to either side)
+            lane_off = rng.uniform(1.5, 4.0, size=(B, n_ped)) * max(1.0, (n_hyp - 1) / 4.0) \
+                * np.where(rng.random(size=(B, n_ped)) < 0.5, -1.0, 1.0)
+            start = xy[:, None, :] + ahead[..., None] * fwd[:, None, :] + lane_off[..., None] * lat[:, None, :]
+            base_ang = np.broadcast_to(th[:, None] + np.pi, (B, n_ped)).copy()
         else:
             raise ValueError(f"unknown ped_mode {ped_mode!r}")
         t = np.arange(N + 1)[None, None, None, :]
