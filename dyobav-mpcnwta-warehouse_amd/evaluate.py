@@ -45,6 +45,46 @@ class EvaluationResult:
     solve_ms: List[float]        # kernel time of every batched solve
 
 
+def action_smoothness(A):
+    """``main_pre.calc_action_smoothness`` (main_pre.py:34-37) for a batch: mean |second difference| of (v, w) over the
+    actions taken; ``A`` [B, T, 2] torch tensor, NaN rows = steps after the run ended. Returns [B, 2] (NaN for T < 3)."""
+    import torch
+    B = A.shape[0]
+    smooth = torch.full((B, 2), float("nan"), dtype=A.dtype, device=A.device)
+    if A.shape[1] >= 3:
+        d2 = (A[:, 2:] - 2 * A[:, 1:-1] + A[:, :-2]).abs()
+        valid = ~torch.isnan(d2[..., 0])
+        smooth = torch.nan_to_num(d2, nan=0.0).sum(dim=1) / valid.sum(dim=1).clamp(min=1)[:, None].to(A.dtype)
+    return smooth
+
+
+def min_dynamic_distance(robot_xy, humans):
+    """``main_pre.calc_minimal_dynamic_obstacle_distance`` (main_pre.py:45-47): [B] distance from the robot to its
+    closest pedestrian; ``robot_xy`` [B, 2], ``humans`` [B, H, 2]."""
+    import torch
+    return torch.linalg.norm(robot_xy[:, None, :] - humans, dim=-1).min(dim=1).values
+
+
+def deviation_to_reference(robot_xy, ref_traj, ref_len):
+    """One term of ``main_pre.calc_deviation_distance`` (main_pre.py:49-53): [B] distance from the robot position to
+    the closest point of its reference trajectory (``ref_traj`` [B, L, 2+], first ``ref_len[b]`` rows valid)."""
+    import torch
+    d = torch.cdist(robot_xy[:, None, :], ref_traj[:, :, :2])[:, 0]
+    inf = torch.full_like(d, float("inf"))
+    return torch.where(torch.arange(d.shape[1], device=d.device)[None] < ref_len[:, None], d, inf).min(dim=1).values
+
+
+def unicycle_rk4_step(robot, act, ts):
+    """``basic_agent.Robot.one_step`` = ``UnicycleModel(ts, rk4=True)`` (basic_motion_model/motion_model.py:141-163) in
+    closed form for a batch: ``robot`` [B, 3], ``act`` [B, 2] -> [B, 3]."""
+    import torch
+    th, v, w = robot[:, 2], act[:, 0], act[:, 1]
+    hh = 0.5 * ts * w
+    cc = (torch.cos(th) + 4 * torch.cos(th + hh) + torch.cos(th + 2 * hh)) / 6
+    ss = (torch.sin(th) + 4 * torch.sin(th + hh) + torch.sin(th + 2 * hh)) / 6
+    return torch.stack([robot[:, 0] + ts * v * cc, robot[:, 1] + ts * v * ss, th + ts * w], dim=1)
+
+
 class BatchEvaluator:
     def __init__(self, config: _capi.NmpcConfigStruct, robot_starts: np.ndarray, robot_paths: Sequence[Sequence[tuple]],
                  human_starts: np.ndarray, human_paths: np.ndarray, map_polygons: np.ndarray, dtype=np.float64,
@@ -57,6 +97,15 @@ class BatchEvaluator:
         self.dt = np.dtype(dtype)
         self.tdt = torch.float32 if self.dt == np.float32 else torch.float64
         self.dev = torch.device("cuda", config.device_id)
+        if config.latency_waves == 0 and (robot_starts.shape[0] > 1024 if compact is None else compact):
+            # The batch shrinks as scenarios finish (compaction) and the library's automatic choice between its two
+            # solver kernels follows the batch size; the kernels agree to rounding only, so the choice is fixed here
+            # from the initial batch: a scenario's closed-loop trajectory must not depend on who else is still running.
+            import copy
+            config = copy.copy(config)
+            n_simd = 4 * self.torch.cuda.get_device_properties(self.dev).multi_processor_count
+            config.latency_waves = 1 if robot_starts.shape[0] > 4 * n_simd else 2
+            self.cfg = config
         self.h = _capi.Handle(config)
         self.h.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
         self.N, self.ts = config.N_hor, config.ts
@@ -75,6 +124,9 @@ class BatchEvaluator:
         self.warm_start = warm_start       # row f4 (extension): shifted previous solution as the initial guess
         self.compact = (robot_starts.shape[0] > 1024) if compact is None else bool(compact)
         self.gen = torch.Generator(device=self.dev).manual_seed(seed)
+        # replay hook for tests: a list of [B, H] tensors, one per pedestrian step, used instead of the generator
+        # (the reference draws the stagger with python's `random`, basic_agent.py:64; a recording can be replayed)
+        self.stagger_replay: Optional[list] = None
         scale = {"safe": 0.2, "work": 0.8, "super": 1.0}[mode]
         self.base_speed = lin_vel_max * scale
         self.lin_vel_max = lin_vel_max
@@ -164,7 +216,9 @@ class BatchEvaluator:
         tgt = torch.gather(self.hpath, 2, self.hidx.clamp(max=W - 1)[..., None, None].expand(-1, -1, 1, 2))[:, :, 0]
         dist = torch.linalg.norm(tgt - self.humans, dim=-1).clamp(min=1e-12)
         dire = (tgt - self.humans) / dist[..., None]
-        if self.stagger > 0:
+        if self.stagger_replay is not None:
+            st = self.stagger_replay.pop(0).to(self.tdt)[..., None]
+        elif self.stagger > 0:
             sign = torch.randint(0, 2, dist.shape, generator=self.gen, device=self.dev) * 2 - 1
             mag = torch.randint(0, 11, dist.shape, generator=self.gen, device=self.dev).to(self.tdt) / 10
             st = (sign.to(self.tdt) * mag * self.stagger)[..., None]
@@ -234,11 +288,7 @@ class BatchEvaluator:
             solve_ms.append(self.h.last_kernel_ms())
             raw = self.U[:, :2].clone()
             act = torch.where((raw[:, 0:1] < 0), torch.zeros_like(raw), raw)     # no-backward, main_base.py:320-321
-            th, v, w = self.robot[:, 2], act[:, 0], act[:, 1]
-            hh = 0.5 * ts * w
-            cc = (torch.cos(th) + 4 * torch.cos(th + hh) + torch.cos(th + 2 * hh)) / 6
-            ss = (torch.sin(th) + 4 * torch.sin(th + hh) + torch.sin(th + 2 * hh)) / 6
-            new_robot = torch.stack([self.robot[:, 0] + ts * v * cc, self.robot[:, 1] + ts * v * ss, th + ts * w], dim=1)
+            new_robot = unicycle_rk4_step(self.robot, act, ts)
             self.robot = torch.where(alive[:, None], new_robot, self.robot)
             last_u = torch.where(alive[:, None], raw, last_u)
             self._step_humans()
@@ -246,12 +296,10 @@ class BatchEvaluator:
             traj.append(self.robot.clone())
             acts.append(torch.where(alive[:, None], raw, torch.full_like(raw, float("nan"))))
             # metrics and flags (main_base.py:326-335)
-            dd = torch.linalg.norm(self.robot[:, None, :2] - self.humans, dim=-1).min(dim=1).values
+            dd = min_dynamic_distance(self.robot[:, :2], self.humans)
             clr_dyn = torch.where(alive, torch.minimum(clr_dyn, dd), clr_dyn)
             clr_stc = torch.where(alive, torch.minimum(clr_stc, self._polygon_distance(self.robot[:, :2])), clr_stc)
-            dref = torch.cdist(self.robot[:, None, :2], self.ref_traj[:, :, :2])[:, 0]
-            dref = torch.where(torch.arange(dref.shape[1], device=self.dev)[None] < self.ref_len[:, None], dref,
-                               torch.full_like(dref, float("inf"))).min(dim=1).values
+            dref = deviation_to_reference(self.robot[:, :2], self.ref_traj, self.ref_len)
             dev_sum = dev_sum + torch.where(alive, dref, torch.zeros_like(dref))
             dev_max = torch.where(alive, torch.maximum(dev_max, dref), dev_max)
             n_traj = n_traj + alive.to(self.tdt)
@@ -263,11 +311,7 @@ class BatchEvaluator:
             alive = alive & ~col & ~done
         collision |= alive                                                       # time-out, main_base.py:407-410
         A = torch.stack(acts, dim=1) if acts else torch.zeros(B, 0, 2, dtype=self.tdt, device=self.dev)
-        smooth = torch.full((B, 2), float("nan"), dtype=self.tdt, device=self.dev)
-        if A.shape[1] >= 3:
-            d2 = (A[:, 2:] - 2 * A[:, 1:-1] + A[:, :-2]).abs()
-            valid = ~torch.isnan(d2[..., 0])
-            smooth = torch.nan_to_num(d2, nan=0.0).sum(dim=1) / valid.sum(dim=1).clamp(min=1)[:, None].to(self.tdt)
+        smooth = action_smoothness(A)
         return EvaluationResult(
             collision=collision.cpu().numpy(), complete=complete.cpu().numpy(), steps=steps.cpu().numpy(),
             smoothness=smooth.cpu().numpy(), clearance=clr_stc.cpu().numpy(), clearance_dyn=clr_dyn.cpu().numpy(),

@@ -37,6 +37,7 @@ import numpy as np
 import yaml
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE            # main(out_dir) may redirect the outputs (the reproducibility test regenerates into a temp dir)
 REF = "/root/reference"
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(REF, "src"))
@@ -317,17 +318,20 @@ def tracker_harness():
     return rec
 
 
-def main():
+def main(out_dir=None):
+    global OUT
+    OUT = out_dir or HERE
+    os.makedirs(OUT, exist_ok=True)
     ka = known_answers()
-    with open(os.path.join(HERE, "known_answers.json"), "w") as fh:
+    with open(os.path.join(OUT, "known_answers.json"), "w") as fh:
         json.dump(ka, fh, indent=1)
     print("known_answers.json:", len(ka), "cases (all match the values asserted by the reference's tests)")
 
     fx, meta = problem_fixture(os.path.join(REF, "config", "mpc_fast.yaml"), K=24, seed=20241016)
-    np.savez_compressed(os.path.join(HERE, "problem_n20.npz"), **fx)
+    np.savez_compressed(os.path.join(OUT, "problem_n20.npz"), **fx)
     print("problem_n20.npz:", fx["P"].shape, "np/n1/n2 =", meta["np"], meta["n1"], meta["n2"],
           "| f range", fx["f"].min(), fx["f"].max(), "| F2>0 in", int((fx["F2"] > 0).any(axis=1).sum()), "cases")
-    with open(os.path.join(HERE, "problem_meta.json"), "w") as fh:
+    with open(os.path.join(OUT, "problem_meta.json"), "w") as fh:
         json.dump(meta, fh, indent=1)
 
     with open(os.path.join(REF, "config", "mpc_fast.yaml")) as fh:
@@ -337,30 +341,31 @@ def main():
     with open(tmp, "w") as fh:
         yaml.safe_dump(y, fh)
     fx2, meta2 = problem_fixture(tmp, K=12, seed=7)
-    np.savez_compressed(os.path.join(HERE, "problem_small.npz"), **fx2)
+    np.savez_compressed(os.path.join(OUT, "problem_small.npz"), **fx2)
     print("problem_small.npz:", fx2["P"].shape, "np/n1/n2 =", meta2["np"], meta2["n1"], meta2["n2"])
 
-    np.savez_compressed(os.path.join(HERE, "motion_model.npz"), **motion_model_fixture())
+    np.savez_compressed(os.path.join(OUT, "motion_model.npz"), **motion_model_fixture())
     print("motion_model.npz written")
 
     th = tracker_harness()
-    with open(os.path.join(HERE, "tracker_harness.json"), "w") as fh:
+    with open(os.path.join(OUT, "tracker_harness.json"), "w") as fh:
         json.dump(th, fh)
     print("tracker_harness.json:", len(th["steps"]), "steps, len(p) =", len(th["steps"][0]["params"]))
 
     ac = assemble_fixture()
-    with open(os.path.join(HERE, "assemble_cases.json"), "w") as fh:
+    with open(os.path.join(OUT, "assemble_cases.json"), "w") as fh:
         json.dump(ac, fh)
     print("assemble_cases.json:", len(ac), "cases")
 
     hc = hypotheses_fixture()
-    with open(os.path.join(HERE, "hypotheses_cases.json"), "w") as fh:
+    with open(os.path.join(OUT, "hypotheses_cases.json"), "w") as fh:
         json.dump(hc, fh)
     print("hypotheses_cases.json:", len(hc), "cases, n_obs =", [c["n_obs"] for c in hc])
 
-
-if __name__ == "__main__":
-    main()
+    ec = evaluate_fixture()
+    with open(os.path.join(OUT, "evaluate_cases.json"), "w") as fh:
+        json.dump(ec, fh)
+    print("evaluate_cases.json:", {k: (len(v) if hasattr(v, "__len__") else v) for k, v in ec.items()})
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -385,6 +390,9 @@ def assemble_fixture(K=6, seed=77):
                  "                                     solve_time_ms=1.0)\n"
                  "def solver():\n    return _S()\n")
     sys.modules.pop("navi_fast", None)
+    # the tracker appends the RELATIVE entry 'mpc_solver/navi_fast' to sys.path (trajectory_tracker.py:58); the import
+    # system caches a finder for it that still points into tracker_harness()'s directory
+    sys.path_importer_cache.pop(os.path.join("", "mpc_solver", "navi_fast"), None)
     cwd = os.getcwd()
     os.chdir(solver_dir)
     rng = np.random.default_rng(seed)
@@ -468,3 +476,128 @@ def hypotheses_fixture(K=8, seed=123):
         cases.append(dict(cur=cur.tolist(), hypos=hyp.tolist(), n_obs=n_obs, dyn_obs_list=dyn_obs_list,
                           counts=[len(m) for m in mu_list_list]))
     return cases
+
+
+# ---------------------------------------------------------------------------------------------------------
+def evaluate_fixture(seed=2024):
+    """f3 ("next" row, batched closed-loop evaluator): recordings of the reference pieces the evaluator restates --
+      human_walks   basic_agent.Human.run_step (basic_agent.py:52-82) along a node path: states per step and the stagger
+                    drawn by the reference's `random` (python's generator, seeded here) so that it can be replayed
+      cv_cases      CvmpInterface.get_motion_prediction (interfaces/cvmp_interface.py:24-57) on trajectories of 1..8 points
+      metric_cases  main_pre.calc_action_smoothness / calc_minimal_dynamic_obstacle_distance / calc_deviation_distance
+                    (main_pre.py:34-53) on random inputs
+      robot_steps   basic_agent.Robot.one_step (unicycle RK4) on random states / actions
+      scenario_0    main_base.scenario_0 (main_base.py:38-44) + the node coordinates of
+                    data/warehouse_sim_original/mygraph.json, mapped to world coordinates by the reference's
+                    ScaleOffsetReverseTransform with the constants of config/global_setting_warehouse.yaml
+    shapely / skimage / pyclipper are absent here: `main_pre` and `main_base` are NOT imported whole; the three metric
+    functions are taken from main_pre's source by exec of the module with stub `shapely` / `basic_map` modules (they
+    do not touch shapely)."""
+    import random
+    for name, attrs in (("shapely", ()), ("shapely.geometry", ("Polygon", "Point")),
+                        ("basic_map", ()), ("basic_map.map_occupancy", ("OccupancyMap",)),
+                        ("basic_map.graph_basic", ("NetGraph",)), ("basic_map.map_geometric", ("GeometricMap",)),
+                        ("utils_test", ())):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        for a in attrs:
+            if not hasattr(m, a):
+                setattr(m, a, object)
+        if not hasattr(m, "__path__"):
+            m.__path__ = []
+        sys.modules[name] = m
+    with contextlib.redirect_stdout(io.StringIO()):
+        import importlib.util
+        from basic_agent import Human, Robot
+        from interfaces.cvmp_interface import CvmpInterface
+        spec = importlib.util.spec_from_file_location("ref_main_pre", os.path.join(REF, "src", "main_pre.py"))
+        main_pre = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(main_pre)
+        spec = importlib.util.spec_from_file_location("ref_map_tf", os.path.join(REF, "src", "basic_map", "map_tf.py"))
+        map_tf = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(map_tf)
+    rng = np.random.default_rng(seed)
+    ts, vmax = 0.2, 1.5
+    out = {"ts": ts, "human_vmax": vmax}
+
+    walks = []
+    for case, stagger in enumerate((0.0, 0.0, 0.5, 0.5)):
+        random.seed(100 + case)
+        start = rng.uniform(-3, 3, 2)
+        path = [tuple(float(v) for v in start + rng.uniform(-6, 6, 2)) for _ in range(3)]
+        h = Human(np.array(start), ts, radius=0.2, stagger=stagger)
+        h.set_path(list(path))
+        states, staggers, moved = [h.state.tolist()], [], []
+        for _ in range(45):
+            before = np.array(h.state, dtype=float)
+            node = h.coming_path[0] if h.coming_path else None
+            ok = h.run_step(vmax)
+            moved.append(bool(ok))
+            if ok:
+                tgt = np.array(h.coming_path[0])          # node after get_next_goal's pop
+                d = tgt - before
+                dire = d / np.hypot(*d)
+                act = (np.array(h.state) - before) / ts
+                staggers.append(float(act[0] - dire[0] * vmax))
+            else:
+                staggers.append(0.0)
+            states.append(np.array(h.state, dtype=float).tolist())
+        walks.append({"start": start.tolist(), "path": [list(p) for p in path], "stagger": stagger, "states": states,
+                      "stagger_draws": staggers, "moved": moved})
+    out["human_walks"] = walks
+
+    cv = CvmpInterface("mpc_fast.yaml")
+    cases = []
+    for L in (1, 2, 3, 5, 6, 8):
+        traj = np.cumsum(rng.normal(0.2, 0.1, size=(L, 2)), axis=0) + rng.uniform(-4, 4, 2)
+        pos, unc = cv.get_motion_prediction([tuple(p) for p in traj.tolist()])
+        cases.append({"traj": traj.tolist(), "positions": [list(map(float, p)) for p in pos],
+                      "uncertainty": [list(map(float, u)) for u in unc]})
+    out["cv_cases"] = cases
+
+    metrics = []
+    for _ in range(4):
+        T = int(rng.integers(12, 40))
+        actions = [np.array([rng.uniform(-0.5, 1.5), rng.uniform(-0.5, 0.5)]) for _ in range(T)]
+        ref = np.cumsum(rng.uniform(0.1, 0.3, size=(T + 10, 2)), axis=0)
+        act = ref[:T + 1] + rng.normal(0, 0.1, size=(T + 1, 2))
+        state = np.array([*rng.uniform(-2, 2, 2), rng.uniform(-3, 3)])
+        humans = [tuple(rng.uniform(-3, 3, 2)) for _ in range(3)]
+        metrics.append({
+            "actions": [a.tolist() for a in actions], "ref_traj": ref.tolist(), "actual_traj": act.tolist(),
+            "state": state.tolist(), "humans": [list(h) for h in humans],
+            "smoothness": [float(v) for v in main_pre.calc_action_smoothness(actions)],
+            "min_dyn_distance": float(main_pre.calc_minimal_dynamic_obstacle_distance(state, humans)),
+            "deviation": [float(v) for v in main_pre.calc_deviation_distance([tuple(p) for p in ref.tolist()],
+                                                                           [tuple(p) for p in act.tolist()])]})
+    out["metric_cases"] = metrics
+
+    steps = []
+    for _ in range(8):
+        s0 = np.array([*rng.uniform(-5, 5, 2), rng.uniform(-3, 3)])
+        a = np.array([rng.uniform(-0.5, 1.5), rng.uniform(-0.5, 0.5)])
+        r = Robot(s0.copy(), ts, radius=0.5)
+        r.one_step(a)
+        steps.append({"state": s0.tolist(), "action": a.tolist(), "next": [float(v) for v in np.array(r.state).reshape(-1)]})
+    out["robot_steps"] = steps
+
+    # scenario_0 (main_base.py:38-44; copied as data: node ids and sim-world coordinates) + graph nodes in world coordinates
+    graph = json.load(open(os.path.join(REF, "data", "warehouse_sim_original", "mygraph.json")))
+    g = yaml.safe_load(open(os.path.join(REF, "config", "global_setting_warehouse.yaml")))
+    ct = map_tf.ScaleOffsetReverseTransform(scale=g["scale2real"], offsetx_after=g["corner_coords"][0],
+                                            offsety_after=g["corner_coords"][1], y_reverse=~g["image_axis"],
+                                            y_max_before=g["sim_height"])
+    nodes_sim = {k: [float(v[0]), float(v[1])] for k, v in graph["node_dict"].items()}
+    nodes_world = {k: [float(x) for x in ct(np.array(v, dtype=float))] for k, v in nodes_sim.items()}
+    human_start, robot_start = [160.0, 50.0], [235.0, 100.0, -np.pi / 2]
+    out["scenario_0"] = {
+        "human_starts_sim": [human_start], "human_paths": [[9, 32, 16]], "robot_start_sim": robot_start,
+        "robot_path": [16, 32], "nodes_sim": nodes_sim, "nodes_world": nodes_world,
+        "human_starts_world": [[float(x) for x in ct(np.array(human_start))]],
+        "robot_start_world": [float(x) for x in ct(np.array(robot_start[:2]))] + [robot_start[2]],
+        "transform": {"scale": g["scale2real"], "offset": g["corner_coords"], "sim_height": g["sim_height"],
+                      "image_axis": g["image_axis"]}}
+    return out
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else None)

@@ -343,11 +343,41 @@ def test_capacity_hint_same_results_and_safe_failure():
     assert np.isfinite(mixed["U"][:48]).all()
 
 
-def test_other_robots_nonzero_paths():
-    """Non-zero other-robot slots (fleet terms) are read from the parameter vector through the LDS index lists."""
-    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "problem_n20.npz"))
+def test_fleet_terms_on_and_off_on_device(problem_n20):
+    """Other-robot (fleet) terms, mpc_builder.py:86-97 / mpc_cost.py:65-76: evaluated on the device with the non-zero
+    robot slots of the golden inputs (index lists in LDS, positions read from the parameter vector), with the t = 0 set
+    only, with the predictive set only, and with every slot zeroed (the reference's default, where the phantom robots at
+    the origin are folded into a closed form) -- each against the oracle, and the variants must differ from one another."""
+    fx, pr = problem_n20
     L = nm.scenarios.ParamLayout()
-    assert (fx["P"][:, L.c0:L.c0 + 30] != 0).any() and (fx["P"][:, L.c:L.c + 600] != 0).any()
+    P = fx["P"].copy()
+    K = P.shape[0]
+    assert (P[:, L.c0:L.c0 + 30] != 0).any() and (P[:, L.c:L.c + 600] != 0).any()
+    # put half of the instances next to a predicted robot position so that the predictive term is active for them
+    for b in range(0, K, 2):
+        P[b, L.c + 3 * (2 * 20 + 5): L.c + 3 * (2 * 20 + 5) + 2] = P[b, L.s0:L.s0 + 2] + 0.05
+        P[b, L.c0 + 3 * 3: L.c0 + 3 * 3 + 2] = P[b, L.s0:L.s0 + 2] + 0.1
+    variants = {"all": P.copy(), "t0_only": P.copy(), "pred_only": P.copy(), "none": P.copy()}
+    variants["t0_only"][:, L.c:L.c + 600] = 0.0
+    variants["pred_only"][:, L.c0:L.c0 + 30] = 0.0
+    variants["none"][:, L.c0:L.c + 600] = 0.0
+    rng = np.random.default_rng(9)
+    Y, C = rng.normal(size=(K, 40)), rng.uniform(1, 50, K)
+    U = fx["U"] * 0.05                      # short roll-outs stay near the start, where the robots were placed
+    psis = {}
+    with nm.Handle(config_for(pr)) as h:
+        for name, Pv in variants.items():
+            for dtype, tol in ((np.float64, 1e-11), (np.float32, 3e-5)):
+                r = h.eval(Pv, U, Y, C, dtype=dtype)
+                for i in range(K):
+                    v, g = oracle.psi(pr, U[i], C[i], Y[i], Pv[i])
+                    assert r["psi"][i] == pytest.approx(v, rel=tol), (name, dtype, i)
+                    np.testing.assert_allclose(r["grad"][i], g, rtol=0, atol=20 * tol * max(1.0, np.abs(g).max()))
+                if dtype == np.float64:
+                    psis[name] = r["psi"].copy()
+    assert (np.abs(psis["all"] - psis["none"]) > 1e-6).sum() >= K // 2
+    assert (np.abs(psis["t0_only"] - psis["none"]) > 1e-6).any() and (np.abs(psis["pred_only"] - psis["none"]) > 1e-6).any()
+    assert (np.abs(psis["all"] - psis["t0_only"]) > 1e-6).any()
 
 
 def test_config2_full_batch_size_independent_properties():

@@ -14,6 +14,8 @@ import pytest
 
 import oracle
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
 
 def test_known_answers_primitives(golden_dir):
     ka = json.load(open(os.path.join(golden_dir, "known_answers.json")))
@@ -98,3 +100,19 @@ def test_psi_is_f_plus_penalties(problem_n20):
         d2 = np.sum((z - np.clip(z, lo, hi)) ** 2)
         expect = fx["f"][i] + 0.5 * c * (d2 + np.sum(fx["F2"][i] ** 2))
         assert val == pytest.approx(expect, rel=1e-12)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="needs the reference checkout (authoring container)")
+def test_fixture_recipe_regenerates_every_fixture_byte_for_byte(tmp_path):
+    """tests/golden/make_golden.py imports the reference's own Python and rewrites every fixture; the committed files are
+    exactly what it produces (the recipe must run as committed)."""
+    import filecmp
+    import subprocess
+    import sys
+    out = tmp_path / "regen"
+    subprocess.run([sys.executable, os.path.join(GOLDEN, "make_golden.py"), str(out)], check=True, capture_output=True,
+                   timeout=900)
+    names = sorted(f for f in os.listdir(GOLDEN) if f.endswith((".json", ".npz")))
+    assert names == sorted(os.listdir(out))
+    for f in names:
+        assert filecmp.cmp(os.path.join(GOLDEN, f), os.path.join(out, f), shallow=False), f
