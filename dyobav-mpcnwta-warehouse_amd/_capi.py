@@ -57,7 +57,7 @@ class NmpcAssembleArgs(C.Structure):
 
 # every symbol include/nmpc_hip.h declares (checked by the CPU test-suite against the built library)
 EXPORTED_SYMBOLS = (
-    "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_param_len", "nmpc_set_stream", "nmpc_use_own_stream",
+    "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_param_len", "nmpc_set_stream", "nmpc_use_own_stream", "nmpc_set_pointer_mode",
     "nmpc_solve_batch_f32", "nmpc_solve_batch_f64", "nmpc_eval_batch_f32", "nmpc_eval_batch_f64",
     "nmpc_assemble_params_f32", "nmpc_assemble_params_f64",
     "nmpc_hypotheses_to_ellipses_f32", "nmpc_hypotheses_to_ellipses_f64",
@@ -98,6 +98,7 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     lib.nmpc_param_len.argtypes = [vp]
     lib.nmpc_set_stream.argtypes = [vp, vp]
     lib.nmpc_use_own_stream.argtypes = [vp]
+    lib.nmpc_set_pointer_mode.argtypes = [vp, i32]
     for sfx in ("f32", "f64"):
         getattr(lib, "nmpc_solve_batch_" + sfx).argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32]
         getattr(lib, "nmpc_eval_batch_" + sfx).argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp]
@@ -189,6 +190,10 @@ class Handle:
             _check(self._lib.nmpc_use_own_stream(self._h))
         else:
             _check(self._lib.nmpc_set_stream(self._h, C.c_void_p(int(stream_ptr))))
+
+    def set_pointer_mode(self, mode: int):
+        """0 = classify every array argument per call (default), 1 = all host pointers, 2 = all device pointers."""
+        _check(self._lib.nmpc_set_pointer_mode(self._h, int(mode)))
 
     def selftest(self) -> int:
         return _check(self._lib.nmpc_selftest(self._h))

@@ -163,6 +163,7 @@ struct nmpc_handle_s {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    int ptr_mode = NMPC_PTR_DETECT;
     DevBuf dP, dU, dcost, dstatus, diters, du0, dy, dc0, dinfo, dY2, dC2, dpsi, dgrad, df2, dws;
 };
 
@@ -371,7 +372,7 @@ int stage_in(nmpc_handle_s* h, DevBuf& buf, const T* src, size_t count, const T*
         *out = nullptr;
         return 0;
     }
-    if (is_device_ptr(src)) {
+    if (h->ptr_mode == NMPC_PTR_DEVICE || (h->ptr_mode == NMPC_PTR_DETECT && is_device_ptr(src))) {
         *out = src;
         return 0;
     }
@@ -381,14 +382,14 @@ int stage_in(nmpc_handle_s* h, DevBuf& buf, const T* src, size_t count, const T*
     return 0;
 }
 template <typename T>
-int stage_out(DevBuf& buf, T* dst, size_t count, T** dev, bool* is_host)
+int stage_out(nmpc_handle_s* h, DevBuf& buf, T* dst, size_t count, T** dev, bool* is_host)
 {
     *is_host = false;
     if (!dst) {
         *dev = nullptr;
         return 0;
     }
-    if (is_device_ptr(dst)) {
+    if (h->ptr_mode == NMPC_PTR_DEVICE || (h->ptr_mode == NMPC_PTR_DETECT && is_device_ptr(dst))) {
         *dev = dst;
         return 0;
     }
@@ -423,13 +424,13 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
     if ((rc = stage_in(h, h->dP, P, (size_t)B * np, &k.P))) return rc;
     if ((rc = stage_in(h, h->du0, u0, (size_t)B * n, &k.u0))) return rc;
     if ((rc = stage_in(h, h->dc0, c0, (size_t)B, &k.c0v))) return rc;
-    if ((rc = stage_out(h->dU, U, (size_t)B * n, &k.U, &hU))) return rc;
-    if ((rc = stage_out(h->dcost, cost, (size_t)B, &k.cost, &hcost))) return rc;
-    if ((rc = stage_out(h->dstatus, status, (size_t)B, &k.status, &hstatus))) return rc;
-    if ((rc = stage_out(h->diters, iters, (size_t)B * 2, &k.iters, &hiters))) return rc;
-    if ((rc = stage_out(h->dy, y, (size_t)B * n, &k.y, &hy))) return rc;
+    if ((rc = stage_out(h, h->dU, U, (size_t)B * n, &k.U, &hU))) return rc;
+    if ((rc = stage_out(h, h->dcost, cost, (size_t)B, &k.cost, &hcost))) return rc;
+    if ((rc = stage_out(h, h->dstatus, status, (size_t)B, &k.status, &hstatus))) return rc;
+    if ((rc = stage_out(h, h->diters, iters, (size_t)B * 2, &k.iters, &hiters))) return rc;
+    if ((rc = stage_out(h, h->dy, y, (size_t)B * n, &k.y, &hy))) return rc;
     const size_t info_row = 8 + nmpc::kProfSlots; // 8 in the shipped library (kProfSlots = 0)
-    if ((rc = stage_out(h->dinfo, info, (size_t)B * info_row, &k.info, &hinfo))) return rc;
+    if ((rc = stage_out(h, h->dinfo, info, (size_t)B * info_row, &k.info, &hinfo))) return rc;
     if (hy && y_is_input) HIP_TRY(hipMemcpyAsync(k.y, y, (size_t)B * n * sizeof(T), hipMemcpyHostToDevice, h->stream));
 
     // latency mode (several wavefronts per instance) pays off while the batch leaves SIMDs idle
@@ -515,9 +516,9 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
     if ((rc = stage_in(h, h->du0, U, (size_t)B * n, &ep.U))) return rc;
     if ((rc = stage_in(h, h->dY2, Y, (size_t)B * n, &ep.Y))) return rc;
     if ((rc = stage_in(h, h->dC2, C, (size_t)B, &ep.C))) return rc;
-    if ((rc = stage_out(h->dpsi, psi, (size_t)B, &ep.psi, &hpsi))) return rc;
-    if ((rc = stage_out(h->dgrad, grad, (size_t)B * n, &ep.grad, &hgrad))) return rc;
-    if ((rc = stage_out(h->df2, f2sq, (size_t)B, &ep.f2sq, &hf2))) return rc;
+    if ((rc = stage_out(h, h->dpsi, psi, (size_t)B, &ep.psi, &hpsi))) return rc;
+    if ((rc = stage_out(h, h->dgrad, grad, (size_t)B * n, &ep.grad, &hgrad))) return rc;
+    if ((rc = stage_out(h, h->df2, f2sq, (size_t)B, &ep.f2sq, &hf2))) return rc;
     const size_t lds_bytes = (size_t)L.lds_total * sizeof(T);
     EvalFn<T> fn = pick_eval<T>(h->lps, L.glb, L.rs);
     hipLaunchKernelGGL(fn, dim3(B), dim3(64), lds_bytes, h->stream, k, ep);
@@ -581,11 +582,13 @@ int assemble_params(nmpc_handle_s* h, const nmpc_assemble_args* g, int32_t B, T*
         return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_assemble_params: every array must be a device pointer");
     const size_t lds = (size_t)a.M * sizeof(T) + (size_t)a.Nstc * sizeof(int) + 16;
     if (lds > kLdsLimit) return fail(NMPC_ERR_UNSUPPORTED, "%d map polygons do not fit the selection kernel's LDS", a.M);
-    HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(nmpc::select_static_kernel<T>, dim3(B), dim3(64), lds, h->stream, a);
+    // (every argument is validated before the first launch)
     const unsigned per_block = 256u * nmpc::kFillPerLane, nchunk = ((unsigned)a.np + per_block - 1) / per_block;
     if ((unsigned long long)B * nchunk >= (1ull << 31))
         return fail(NMPC_ERR_UNSUPPORTED, "B = %d too large for one assembly call; split the batch", B);
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(nmpc::select_static_kernel<T>, dim3(B), dim3(64), lds, h->stream, a);
+    HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(nmpc::fill_kernel<T>, dim3((unsigned)B * nchunk), dim3(256), 0, h->stream, a, nchunk);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
@@ -798,6 +801,14 @@ int nmpc_set_stream(nmpc_handle h, void* s)
 {
     if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
     h->stream = static_cast<hipStream_t>(s); // NULL is a stream too: the HIP null stream (torch's default stream)
+    return 0;
+}
+
+int nmpc_set_pointer_mode(nmpc_handle h, int32_t mode)
+{
+    if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (mode < NMPC_PTR_DETECT || mode > NMPC_PTR_DEVICE) return fail(NMPC_ERR_INVALID_ARGUMENT, "pointer mode %d", mode);
+    h->ptr_mode = mode;
     return 0;
 }
 

@@ -30,9 +30,11 @@ def make_config(mpc_config=None, robot_spec=None, device_id: int = 0, **override
     ``configs.CircularRobotSpecification``); unspecified values are the OpEn defaults the reference builds with
     (``solver_build/mpc_builder.py:187-195``).
 
-    ``max_solver_time`` (a wall-clock cap in the reference) has no counterpart: a GPU batch cannot stop single
-    instances on a timer, so termination is by OpEn's iteration caps only (``max_outer_iterations`` x
-    ``max_inner_iterations``); pass smaller caps through ``overrides`` to bound latency.
+    ``max_solver_time`` (micro-seconds; ``with_max_duration_micros``, ``mpc_builder.py:189``) becomes
+    ``nmpc_config.max_solver_time_us``: every instance checks the GPU's real-time counter once per inner iteration and
+    before every outer iteration, exactly where OpEn checks its clock, and reports ``NotConvergedOutOfTime`` when the
+    budget is used up (``bad_exit_codes`` of the yaml files, ``trajectory_tracker.py:334-335``). For the shipped
+    0.1 s a solve of one problem (~3 ms) never gets near it.
     """
     cfg = default_config_struct()
     cfg.device_id = device_id
@@ -43,6 +45,8 @@ def make_config(mpc_config=None, robot_spec=None, device_id: int = 0, **override
                 int(mpc_config.nstcobs) != 12 or int(mpc_config.ndynobs) != 6:
             raise ValueError("the kernels implement ns=3, nu=2, nq=10, nstcobs=12, ndynobs=6 (the shipped yaml values)")
         cfg.ts = float(mpc_config.ts)
+        if getattr(mpc_config, "max_solver_time", None):
+            cfg.max_solver_time_us = float(mpc_config.max_solver_time)
     if robot_spec is not None:
         for k in _ROBOT_FIELDS:
             setattr(cfg, k, float(getattr(robot_spec, k)))
@@ -87,14 +91,24 @@ class Solver:
         self._handle = Handle(self.config)
         self.num_parameters = self._handle.np_
         self.num_decision_variables = self._handle.n
-        self._y = np.zeros((1, self._handle.n), dtype=self.dtype)
+        n = self._handle.n
+        self._y = np.zeros((1, n), dtype=self.dtype)
+        # persistent host buffers of the B = 1 path + "all arguments are host pointers": no per-call allocation and no
+        # hipPointerGetAttributes lookups (12 per call before; the host side of a solve was 1.7 ms of 2.4 ms)
+        self._handle.set_pointer_mode(1)
+        self._bufs = dict(P=np.empty((1, self.num_parameters), dtype=self.dtype), U=np.empty((1, n), dtype=self.dtype),
+                          cost=np.empty(1, dtype=self.dtype), status=np.empty(1, dtype=np.int32),
+                          iters=np.empty((1, 2), dtype=np.int32), y=np.zeros((1, n), dtype=self.dtype),
+                          info=np.empty((1, 8), dtype=self.dtype), u0=np.empty((1, n), dtype=self.dtype),
+                          c0=np.empty(1, dtype=self.dtype))
 
     def run(self, p, initial_guess=None, initial_lagrange_multipliers=None, initial_penalty=None):
-        p = np.asarray(p, dtype=self.dtype).reshape(1, -1)
         n = self.num_decision_variables
-        if p.shape[1] != self.num_parameters:
-            print(f"1600 -> wrong number of parameters: expected {self.num_parameters}, got {p.shape[1]}")
+        if len(p) != self.num_parameters:
+            print(f"1600 -> wrong number of parameters: expected {self.num_parameters}, got {len(p)}")
             return None
+        b = self._bufs
+        b["P"][0, :] = p
         u0 = None
         if initial_guess is not None:
             u0 = np.asarray(initial_guess, dtype=self.dtype).reshape(1, -1)
@@ -112,10 +126,19 @@ class Solver:
             y = self._y.copy()
         else:
             y = np.zeros((1, n), dtype=self.dtype)
-        c0 = None if initial_penalty is None else np.asarray([initial_penalty], dtype=self.dtype)
+        c0 = None
+        if initial_penalty is not None:
+            b["c0"][0] = initial_penalty
+            c0 = b["c0"]
+        if u0 is not None:
+            b["u0"][:] = u0
+            u0 = b["u0"]
+        b["y"][:] = y
         tic = time.perf_counter()
-        out = self._handle.solve(p, u0=u0, y0=y, c0=c0, dtype=self.dtype)
+        self._handle.solve_raw(self.dtype, b["P"], 1, b["U"], b["cost"], b["status"], b["iters"], u0, b["y"], True, c0,
+                               b["info"], True)
         wall_ms = (time.perf_counter() - tic) * 1e3
+        out = dict(U=b["U"].copy(), cost=b["cost"], status=b["status"], iters=b["iters"], y=b["y"].copy(), info=b["info"])
         status = int(out["status"][0])
         if status == 3:  # OpEn: Err(NotFiniteComputation) -> binding returns None
             print("2000 -> Problem solution failed")

@@ -38,6 +38,9 @@ def _error(code: int, message: str) -> dict:
     return {"type": "Error", "code": code, "message": message}
 
 
+CLIENT_TIMEOUT_S = 10.0   # per-connection receive / send timeout of the server
+
+
 def _answer(sol) -> dict:
     return {"exit_status": sol.exit_status, "num_outer_iterations": sol.num_outer_iterations,
             "num_inner_iterations": sol.num_inner_iterations, "last_problem_norm_fpr": sol.last_problem_norm_fpr,
@@ -46,8 +49,21 @@ def _answer(sol) -> dict:
             "lagrange_multipliers": list(sol.lagrange_multipliers), "cost": sol.cost}
 
 
+def _is_number_list(x, length=None) -> bool:
+    return isinstance(x, (list, tuple)) and (length is None or len(x) == length) and \
+        all(isinstance(v, (int, float)) and not isinstance(v, bool) for v in x)
+
+
 def handle_request(solver, text: str):
-    """One request document -> (answer dict or None, keep_running)."""
+    """One request document -> (answer dict or None, keep_running). Never raises: a malformed but valid-JSON request
+    (wrong types, non-numeric entries) is answered with the 1000 "Invalid request" error like any other bad document."""
+    try:
+        return _handle_request(solver, text)
+    except Exception as exc:   # the accept loop must survive whatever a client sends
+        return _error(ERR_INVALID_REQUEST, f"Invalid request ({type(exc).__name__})"), True
+
+
+def _handle_request(solver, text: str):
     try:
         req = json.loads(text)
     except ValueError:
@@ -61,6 +77,13 @@ def handle_request(solver, text: str):
     n, np_ = solver.num_decision_variables, solver.num_parameters
     if "Run" in req and isinstance(req["Run"], dict) and "parameter" in req["Run"]:
         r = req["Run"]
+        if not _is_number_list(r["parameter"]):
+            return _error(ERR_INVALID_REQUEST, "Invalid request"), True
+        for opt in ("initial_guess", "initial_lagrange_multipliers"):
+            if r.get(opt) is not None and not _is_number_list(r[opt]):
+                return _error(ERR_INVALID_REQUEST, "Invalid request"), True
+        if r.get("initial_penalty") is not None and not isinstance(r["initial_penalty"], (int, float)):
+            return _error(ERR_INVALID_REQUEST, "Invalid request"), True
         if len(r["parameter"]) != np_:
             return _error(ERR_WRONG_PARAMETER, f"wrong number of parameters: provided {len(r['parameter'])}, expected {np_}"), True
         u0, y0 = r.get("initial_guess"), r.get("initial_lagrange_multipliers")
@@ -75,6 +98,8 @@ def handle_request(solver, text: str):
         return _answer(sol), True
     if "RunBatch" in req and isinstance(req["RunBatch"], dict) and "parameter" in req["RunBatch"]:
         rows = req["RunBatch"]["parameter"]
+        if not isinstance(rows, list) or not all(_is_number_list(row) for row in rows):
+            return _error(ERR_INVALID_REQUEST, "Invalid request"), True
         if any(len(row) != np_ for row in rows):
             return _error(ERR_WRONG_PARAMETER, f"wrong number of parameters: expected {np_} per row"), True
         sols = solver.run_many(rows)
@@ -98,15 +123,19 @@ def serve(solver, ip: str = "127.0.0.1", port: int = 8333, ready: Optional[threa
         while running:
             conn, _ = srv.accept()
             with conn:
+                conn.settimeout(CLIENT_TIMEOUT_S)     # a stalled client must not block the (single-threaded) server
                 chunks = []
-                while True:
-                    data = conn.recv(65536)
-                    if not data:
-                        break
-                    chunks.append(data)
-                answer, running = handle_request(solver, b"".join(chunks).decode("utf-8", "replace"))
-                if answer is not None:
-                    conn.sendall(json.dumps(answer).encode())
+                try:
+                    while True:
+                        data = conn.recv(65536)
+                        if not data:
+                            break
+                        chunks.append(data)
+                    answer, running = handle_request(solver, b"".join(chunks).decode("utf-8", "replace"))
+                    if answer is not None:
+                        conn.sendall(json.dumps(answer).encode())
+                except (socket.timeout, OSError):
+                    continue                           # drop this connection, keep serving
     finally:
         srv.close()
 

@@ -97,6 +97,36 @@ def test_error_documents(manager):
     assert mng.ping() == {"Pong": 1}                     # the server survives bad requests
 
 
+def test_malformed_but_valid_json_requests_do_not_kill_the_server(manager):
+    """requests that parse as JSON but carry the wrong types used to raise inside the accept loop (TypeError
+    in len(5), ValueError for non-numeric entries) and leave later clients hanging. They are answered with error 1000."""
+    mng, _ = manager
+    p = ",".join(["0.0"] * 2778)
+    for bad in ('{"Run": {"parameter": 5}}', '{"Run": {"parameter": "abc"}}',
+                '{"Run": {"parameter": [' + ",".join(['"x"'] * 2778) + ']}}',
+                '{"Run": {"parameter": [' + p + '], "initial_guess": 7}}',
+                '{"Run": {"parameter": [' + p + '], "initial_penalty": "big"}}',
+                '{"RunBatch": {"parameter": 3}}', '{"RunBatch": {"parameter": [[1, 2], "row"]}}',
+                '{"Run": {"parameter": [true, false]}}'):
+        d = _raw(mng, bad)
+        assert d["type"] == "Error" and d["code"] == 1000, bad[:40]
+    assert mng.ping() == {"Pong": 1}
+    assert mng.call([0.25] + [0.0] * 2777).is_ok()
+
+
+def test_stalled_client_is_dropped(manager, monkeypatch):
+    """A client that connects and never finishes its request is dropped after the receive timeout instead of blocking
+    the single-threaded server for good."""
+    mng, _ = manager
+    monkeypatch.setattr(tcp, "CLIENT_TIMEOUT_S", 0.3)
+    stalled = socket.create_connection((mng.ip, mng.port), timeout=10)
+    stalled.sendall(b'{"Run": {"parameter": [0.0, ')          # ... and nothing more, no shutdown
+    try:
+        assert mng.ping() == {"Pong": 1}                      # served once the stalled connection has timed out
+    finally:
+        stalled.close()
+
+
 def test_batch_request_extension(manager):
     mng, _ = manager
     P = [[float(i)] + [0.0] * 2777 for i in range(5)]
