@@ -105,7 +105,7 @@ class Env:
 
 
 def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, warmup: int, batch=None,
-                 latency_waves: int = 0, reg_table: int = 0) -> dict:
+                 latency_waves: int = 0, reg_table: int = 0, coop_waves: int = 0) -> dict:
     """Time `steps` passes of one workload (after `warmup` untimed ones); returns the measurements of this rank with
     the whole-job rate (max over ranks of the elapsed time)."""
     torch, dist, nm = env.torch, env.dist, env.nm
@@ -128,6 +128,7 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
     cfg.max_active_dynobs = spec["n_ped"] * spec["n_hyp"]
     cfg.latency_waves = latency_waves
     cfg.reg_table = reg_table
+    cfg.coop_waves = coop_waves
     h = nm.Handle(cfg)
     h.set_stream(torch.cuda.current_stream().cuda_stream)
 
@@ -177,7 +178,8 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
     waves = int(info[0, 7])          # 0: throughput kernel; > 0: latency kernel with that many wavefronts per instance
     tname = "float" if dtype == "f32" else "double"
     lps = kinfo["lanes_per_step"]
-    kernel_name = (f"solve_spec_kernel<{tname}, LPS={lps}> x {waves} wavefronts per instance (latency mode)" if waves
+    kernel_name = (f"solve_spec_kernel<{tname}, LPS={lps}> x {waves} wavefronts per instance (latency mode)" if waves > 0
+                   else f"solve_coop_kernel<{tname}, LPS={lps}> x {-waves} wavefronts sharing each evaluation" if waves < 0
                    else f"solve_kernel<{tname}, LPS={lps}> (one wavefront per instance)")
     flops_launch = float(np.sum((n_psi - n_grad) * ff + n_grad * 3 * ff))
     achieved_tf = flops_launch / (k_ms * 1e-3) / 1e12
@@ -229,6 +231,7 @@ def main():
                     help="nmpc_config.latency_waves: 0 = automatic (library default), 1 = one wavefront per instance, "
                          "2..4 = latency mode")
     ap.add_argument("--reg-table", type=int, default=0, help="nmpc_config.reg_table: 0 = automatic, -1 = LDS / global table")
+    ap.add_argument("--coop-waves", type=int, default=0, help="nmpc_config.coop_waves: 0 = automatic, 1 = off, 2..4")
     args = ap.parse_args()
 
     # stdout must carry exactly ONE JSON line: RCCL / HIP libraries print banners and warnings on fd 1, so keep a
@@ -239,7 +242,7 @@ def main():
 
     env = Env(args)
     m = run_workload(env, args.workload, args.family, args.dtype, args.steps, args.warmup, args.batch,
-                     args.latency_waves, args.reg_table)
+                     args.latency_waves, args.reg_table, args.coop_waves)
     layout, P_host, U, status = m.pop("_host")
 
     if env.rank == 0:

@@ -81,6 +81,7 @@ struct Layout {
     int lds_alpha, lds_poly, lds_seg, lds_seginv, lds_fl0, lds_fl, lds_iflag, lds_hist, lds_rho, lds_total;
     int lds_xch, lds_total_spec; // latency mode: exchange area + the other wavefronts' parking areas behind lds_total
     int lds_park;
+    int lds_xch_coop, lds_total_coop; // cooperative mode: kSpecWaves parking areas, then the partial-sum exchange area
     int dyn_cap;          // obstacle rows provisioned per instance
     int rs;               // > 0: register-resident obstacle table with this many slots per lane (LDS keeps t = 0 only)
     bool glb;             // obstacle table streamed from a global workspace instead of LDS
@@ -139,6 +140,8 @@ Layout make_layout(const nmpc_config& c, size_t elem_size)
     // 2 buffers x kSpecWaves x (64 lanes x 2 gradient entries + psi)
     L.lds_xch = L.lds_park + (L.rs ? kSpecWaves * park_one : 0);
     L.lds_total_spec = L.lds_xch + 2 * kSpecWaves * (2 * 64 + 4);
+    L.lds_xch_coop = L.lds_park + kSpecWaves * park_one;
+    L.lds_total_coop = L.lds_xch_coop + 2 * kSpecWaves * (3 * 64 + 4);
     if (L.glb || (size_t)L.lds_total * elem_size <= kLdsLimit) break;
     L.glb = true; // second attempt: everything but the ellipse table in LDS
     L.ws_stride = (long long)(nmpc::kEllStride + 1) * ne;
@@ -154,6 +157,8 @@ struct nmpc_handle_s {
     int lps;
     int n_simd = 0; // SIMDs of the device (4 per CU): latency_waves = 0 picks the wavefront count from B / n_simd
     bool spec_ok[2] = {true, true}; // [f32, f64]
+    bool coop_ok[2] = {true, true};
+    int last_mode = 0;              // kernel of the last solve: 0 throughput, 1 latency (speculative), 2 cooperative
     template <typename T>
     const Layout& lay() const
     {
@@ -187,6 +192,14 @@ __global__ __launch_bounds__(64, (wpe<T, RS>(NMPC_WPE_F32))) void solve_kernel(n
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     nmpc::solve_instance<T, LPS, GLB, RS>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
+}
+
+// cooperative mode: up to kSpecWaves wavefronts per instance share every evaluation (nmpc_device.h, COOP)
+template <typename T, int LPS, bool GLB>
+__global__ __launch_bounds__(64 * kSpecWaves, (sizeof(T) == 4 ? NMPC_SPEC_WPE_F32 : NMPC_WPE_F64)) void solve_coop_kernel(nmpc::KParams<T> kp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    nmpc::solve_instance<T, LPS, GLB, 0, true>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
 }
 
 // latency mode: kSpecWaves wavefronts per instance, speculative line search (nmpc_spec.h)
@@ -354,6 +367,13 @@ SolveFn<T> pick_solve_spec(int lps, bool glb, int rs = 0)
 }
 
 template <typename T>
+SolveFn<T> pick_solve_coop(int lps, bool glb)
+{
+    if (glb) return lps == 3 ? solve_coop_kernel<T, 3, true> : lps == 2 ? solve_coop_kernel<T, 2, true> : solve_coop_kernel<T, 1, true>;
+    return lps == 3 ? solve_coop_kernel<T, 3, false> : lps == 2 ? solve_coop_kernel<T, 2, false> : solve_coop_kernel<T, 1, false>;
+}
+
+template <typename T>
 EvalFn<T> pick_eval(int lps, bool glb, int rs = 0)
 {
     if constexpr (sizeof(T) == 4) {
@@ -469,8 +489,22 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
     }
     int waves = lw == 1 ? 0 : lw < 0 ? 1 : lw > kSpecWaves ? kSpecWaves : lw;
     if (!h->spec_ok[sizeof(T) == 4 ? 0 : 1]) waves = 0;
-    const size_t lds_bytes = (size_t)(waves ? L.lds_total_spec : L.lds_total) * sizeof(T);
+    // cooperative evaluation (nmpc_config.coop_waves): explicit request, or automatic where the obstacle table is streamed
+    // from global memory (configs[4]: the obstacle loop is 94 % of the time and its rows split cleanly over the
+    // wavefronts). Needs the LDS / global table (not the register table), room for the exchange area and no wall-clock
+    // budget (each wavefront would read its own clock).
+    int coop = h->cfg.coop_waves > kSpecWaves ? kSpecWaves : h->cfg.coop_waves;
+    if (coop == 0) coop = (L.glb && h->cfg.latency_waves == 0) ? kSpecWaves : 1;
+    if (L.rs > 0 || h->cfg.max_solver_time_us > 0 || !h->coop_ok[sizeof(T) == 4 ? 0 : 1]) coop = 1;
+    size_t lds_bytes = (size_t)(waves ? L.lds_total_spec : L.lds_total) * sizeof(T);
     SolveFn<T> fn = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs) : pick_solve<T>(h->lps, L.glb, L.rs);
+    if (coop > 1) {
+        fn = pick_solve_coop<T>(h->lps, L.glb);
+        lds_bytes = (size_t)L.lds_total_coop * sizeof(T);
+        k.lds_xch = L.lds_xch_coop;
+        waves = coop;
+    }
+    h->last_mode = coop > 1 ? 2 : waves ? 1 : 0;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(fn, dim3(B), dim3(waves ? 64 * waves : 64), lds_bytes, h->stream, k);
     HIP_TRY(hipGetLastError());
@@ -640,6 +674,13 @@ int set_lds_limit(nmpc_handle_s* h)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_eval<T>(h->lps, L.glb, L.rs)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
+    const size_t coop_bytes = (size_t)L.lds_total_coop * sizeof(T);
+    if (coop_bytes > kLdsLimit) {
+        h->coop_ok[sizeof(T) == 4 ? 0 : 1] = false;
+    } else if (coop_bytes > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve_coop<T>(h->lps, L.glb)),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_bytes));
+    }
     const size_t spec_bytes = (size_t)L.lds_total_spec * sizeof(T);
     if (spec_bytes > kLdsLimit) {
         h->spec_ok[sizeof(T) == 4 ? 0 : 1] = false; // no room for the exchange area: latency mode unavailable
@@ -723,6 +764,8 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
                     NMPC_LBFGS_MAX_MEMORY);
     if (cfg->latency_waves < -1)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "latency_waves = %d < -1", cfg->latency_waves);
+    if (cfg->coop_waves < 0 || cfg->coop_waves > kSpecWaves)
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "coop_waves = %d outside [0, %d]", cfg->coop_waves, kSpecWaves);
     if (cfg->akkt_form != 0 && cfg->akkt_form != 1)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "akkt_form = %d (0 = OpEn source form, 1 = documented form)", cfg->akkt_form);
     if (!(cfg->max_solver_time_us >= 0))

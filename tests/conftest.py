@@ -45,7 +45,16 @@ def problem_small():
 
 # nmpc_config.latency_waves used by config_for(): test modules that check parity with the oracle run once per solver
 # kernel (1 = throughput kernel, 4 = latency kernel; 0 = the library's automatic choice by batch size)
-KERNEL_MODE = {"latency_waves": 0}
+KERNEL_MODE = {"latency_waves": 0, "coop_waves": 0, "reg_table": 0}
+
+
+def set_kernel_mode(mode):
+    """1 = throughput kernel, 4 = latency kernel (4 wavefronts, speculative line search), "coop" = cooperative kernel
+    (4 wavefronts share every evaluation; needs the LDS / global obstacle table), 0 = the library's automatic choice."""
+    if mode == "coop":
+        KERNEL_MODE.update(latency_waves=1, coop_waves=4, reg_table=-1)
+    else:
+        KERNEL_MODE.update(latency_waves=int(mode), coop_waves=0, reg_table=0)
 
 
 def config_for(pr, **overrides):
@@ -53,6 +62,8 @@ def config_for(pr, **overrides):
     import dyobav_mpcnwta_warehouse_amd as nm
     cfg = nm.default_config_struct()
     cfg.latency_waves = KERNEL_MODE["latency_waves"]
+    cfg.coop_waves = KERNEL_MODE["coop_waves"]
+    cfg.reg_table = KERNEL_MODE["reg_table"]
     cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs = pr.N, pr.Nother, pr.Nstc, pr.Ndyn
     for k in ("ts", "lin_vel_min", "lin_vel_max", "ang_vel_max", "lin_acc_min", "lin_acc_max", "ang_acc_max",
               "vehicle_width", "vehicle_margin", "social_margin"):

@@ -12,11 +12,12 @@ from conftest import config_for
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, scope="module", params=[1, 4], ids=["throughput-kernel", "latency-kernel"])
+@pytest.fixture(autouse=True, scope="module", params=[1, 4, "coop"],
+                ids=["throughput-kernel", "latency-kernel", "cooperative-kernel"])
 def kernel_mode(request):
-    conftest.KERNEL_MODE["latency_waves"] = request.param
+    conftest.set_kernel_mode(request.param)
     yield request.param
-    conftest.KERNEL_MODE["latency_waves"] = 0
+    conftest.set_kernel_mode(0)
 
 
 @pytest.mark.parametrize("akkt_form", [0, 1])

@@ -21,12 +21,13 @@ from conftest import config_for
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, scope="module", params=[1, 4], ids=["throughput-kernel", "latency-kernel"])
+@pytest.fixture(autouse=True, scope="module", params=[1, 4, "coop"],
+                ids=["throughput-kernel", "latency-kernel", "cooperative-kernel"])
 def kernel_mode(request):
     """Every test of this module runs against both solver kernels (separate compilations of the same algorithm)."""
-    conftest.KERNEL_MODE["latency_waves"] = request.param
+    conftest.set_kernel_mode(request.param)
     yield request.param
-    conftest.KERNEL_MODE["latency_waves"] = 0
+    conftest.set_kernel_mode(0)
 
 
 @pytest.fixture(scope="module")
@@ -316,21 +317,22 @@ def test_capacity_hint_same_results_and_safe_failure():
     # automatic mode: 15 provisioned rows -> 14-slot register table, 10 rows -> 4-slot one; separate compilations of the
     # same arithmetic agree to rounding (and both with the LDS-table kernel). Compared after 5 inner iterations, before
     # the iteration amplifies fp32 rounding (DESIGN.md "parity protocol"); full solves: same statuses, similar costs.
-    short = dict(max_outer_iterations=1, max_inner_iterations=5)
-    with nm.Handle(config_for(pr, reg_table=-1, **short)) as h:
-        s_lds = h.solve(P)
-    with nm.Handle(config_for(pr, **short)) as h:
-        s15 = h.solve(P)
-        assert h.kernel_info()["lds_bytes_f32"] < lds_full          # only the t = 0 snapshot is in LDS
-    with nm.Handle(config_for(pr, max_active_dynobs=10, **short)) as h:
-        s10 = h.solve(P)
-    for a, b in ((s15, s10), (s15, s_lds)):
-        assert np.array_equal(a["iters"], b["iters"])
-        du = np.abs(a["U"] - b["U"]).max(axis=1)
-        assert np.median(du) < 2e-4 and du.max() < 5e-2, (np.median(du), du.max())
-    with nm.Handle(config_for(pr)) as h:
-        auto15 = h.solve(P)
-    assert np.mean(auto15["status"] == full["status"]) >= 0.9 and np.isfinite(auto15["U"]).all()
+    if conftest.KERNEL_MODE["reg_table"] == 0:      # (the cooperative kernel always uses the LDS / global table)
+        short = dict(max_outer_iterations=1, max_inner_iterations=5)
+        with nm.Handle(config_for(pr, reg_table=-1, **short)) as h:
+            s_lds = h.solve(P)
+        with nm.Handle(config_for(pr, **short)) as h:
+            s15 = h.solve(P)
+            assert h.kernel_info()["lds_bytes_f32"] < lds_full          # only the t = 0 snapshot is in LDS
+        with nm.Handle(config_for(pr, max_active_dynobs=10, **short)) as h:
+            s10 = h.solve(P)
+        for a, b in ((s15, s10), (s15, s_lds)):
+            assert np.array_equal(a["iters"], b["iters"])
+            du = np.abs(a["U"] - b["U"]).max(axis=1)
+            assert np.median(du) < 2e-4 and du.max() < 5e-2, (np.median(du), du.max())
+        with nm.Handle(config_for(pr)) as h:
+            auto15 = h.solve(P)
+        assert np.mean(auto15["status"] == full["status"]) >= 0.9 and np.isfinite(auto15["U"]).all()
     for rt in (0, -1):
         with nm.Handle(config_for(pr, max_active_dynobs=9, reg_table=rt)) as h:
             small = h.solve(P)
