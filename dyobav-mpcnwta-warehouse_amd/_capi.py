@@ -43,7 +43,7 @@ class NmpcConfigStruct(C.Structure):
         ("cbfgs_alpha", C.c_double), ("cbfgs_epsilon", C.c_double), ("sy_epsilon", C.c_double),
         ("latency_waves", C.c_int32), ("akkt_form", C.c_int32),
         ("max_solver_time_us", C.c_double),
-        ("coop_waves", C.c_int32), ("lbfgs_gram", C.c_int32), ("reg_table", C.c_int32), ("reserved0", C.c_int32),
+        ("coop_waves", C.c_int32), ("reserved1", C.c_int32), ("reg_table", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -176,7 +176,7 @@ namespace {
 
 // second launch-bound argument = minimum waves per SIMD; it caps the register allocation (512 / waves)
 #ifndef NMPC_WPE_F32
-#define NMPC_WPE_F32 4 // throughput kernel, table in LDS / global memory: fits 128 VGPRs without spilling
+#define NMPC_WPE_F32 3 // throughput kernel, table in LDS / global memory (133 VGPRs; one spill short of fitting 128)
 #endif
 #ifndef NMPC_WPE_F64
 #define NMPC_WPE_F64 2
@@ -740,7 +740,7 @@ int nmpc_default_config(nmpc_config* c)
     c->akkt_form = 0;
     c->max_solver_time_us = 0.0;
     c->coop_waves = 0;
-    c->lbfgs_gram = 0;
+    c->reserved1 = 0;
     c->reg_table = 0;
     return 0;
 }
@@ -770,7 +770,7 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "akkt_form = %d (0 = OpEn source form, 1 = documented form)", cfg->akkt_form);
     if (!(cfg->max_solver_time_us >= 0))
         return fail(NMPC_ERR_INVALID_ARGUMENT, "max_solver_time_us < 0");
-    if (cfg->reserved0 != 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "reserved fields must be 0");
+    if (cfg->reserved0 != 0 || cfg->reserved1 != 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "reserved fields must be 0");
     if (!(cfg->ts > 0) || cfg->max_outer_iterations < 1 || cfg->max_inner_iterations < 1 ||
         !(cfg->initial_penalty > 0))
         return fail(NMPC_ERR_INVALID_ARGUMENT, "bad ts / iteration caps / initial penalty");

@@ -88,20 +88,20 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     LaneVec<T> rho; // rho_i by physical slot (every wavefront keeps its own, identical copy)
     T osv = 0, osw = 0, ogv = 0, ogw = 0, lb_gamma = 1;
     int lb_active = 0, lb_head = 0;
-    bool lb_first = true;
+    int lb_first = 1; // (the wave-uniform flags are ints: a bool would live in an SGPR PAIR as a lane mask)
     T dyn = 0, dyn_plus = 0, f2n = 0, f2n_plus = 0;
     int alm_iter = 0, inner_total = 0, outer = 1, status = 0;
     int num_iter = 0, lip_it = 0, nls = 0;
-    bool cont = true;
+    int cont = 1;
     T cost_half = 0, normh = 0, fbe_cur = 0;
-    bool fbe_valid = false;
+    int fbe_valid = 0;
     int alg_psi = 0, alg_grad = 0, rounds = 0; // evaluations the sequential algorithm performs / exchange rounds
     // max_solver_time: wavefront 0 publishes its elapsed real-time ticks with every exchange round, so that all
     // wavefronts of the workgroup take the same decision (see solve_instance)
     const long long time_budget = cold_args<T>()->time_budget;
     const long long t_start = time_budget > 0 ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
     int t_now = 0;
-    bool cont_time = true;
+    int cont_time = 1;
 
     // exchange area: 2 buffers x W wavefronts x (64 lanes x (g_v, g_w) + psi, padded to 4). Per lane, not per step:
     // the LPS lanes of a step hold copies of the step's scalars that may differ in the last bit (each lane's
@@ -161,7 +161,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     int phase = SP_INIT_A;
     T ev = uv, ew = uw, ec = c;
     T inv_cdiv = T(1) / (c > T(1) ? c : T(1));
-    bool want_grad = true, do_eval = true, exchange = false;
+    int want_grad = 1, do_eval = 1, exchange = 0;
     T r_psi = 0, r_f2 = 0, r_gv = 0, r_gw = 0;
 
     // every wavefront evaluates the same request (results used locally, no exchange)
@@ -191,7 +191,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     // The integer / boolean solver state is the same in every lane by construction; telling the compiler so (a
     // v_readfirstlane each) turns the state machine's control flow into scalar branches instead of lane-mask algebra.
     auto uni = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
-    auto unib = [](bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; };
+    auto unib = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
     for (;;) {
         phase = uni(phase);
         iteration = uni(iteration);
@@ -410,23 +410,25 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 bool finite = tfinite(uv) && tfinite(uw) && tfinite(f_u);
                 if (__ballot(!finite) != 0ull) status = 3;
                 if (wave == 0) {
+                    int ri = inst; // (opaque: result-row offsets computed here, not kept in SGPRs for the whole solve)
+                    asm volatile("" : "+s"(ri));
                     if (lead) {
-                        kc->U[(size_t)inst * 2 * N + 2 * I.k] = uv;
-                        kc->U[(size_t)inst * 2 * N + 2 * I.k + 1] = uw;
+                        kc->U[(size_t)ri * 2 * N + 2 * I.k] = uv;
+                        kc->U[(size_t)ri * 2 * N + 2 * I.k + 1] = uw;
                         if (kc->y) {
-                            kc->y[(size_t)inst * 2 * N + I.k] = yv;
-                            kc->y[(size_t)inst * 2 * N + N + I.k] = yw;
+                            kc->y[(size_t)ri * 2 * N + I.k] = yv;
+                            kc->y[(size_t)ri * 2 * N + N + I.k] = yw;
                         }
                     }
                     if (I.lane == 0) {
-                        if (kc->cost) kc->cost[inst] = f_u;
-                        if (kc->status) kc->status[inst] = status;
+                        if (kc->cost) kc->cost[ri] = f_u;
+                        if (kc->status) kc->status[ri] = status;
                         if (kc->iters) {
-                            kc->iters[2 * inst] = outer;
-                            kc->iters[2 * inst + 1] = inner_total;
+                            kc->iters[2 * ri] = outer;
+                            kc->iters[2 * ri + 1] = inner_total;
                         }
                         if (kc->info) {
-                            T* o = kc->info + (size_t)inst * (8 + kProfSlots);
+                            T* o = kc->info + (size_t)ri * (8 + kProfSlots);
                             o[0] = norm_fpr;
                             o[1] = f2n_plus;
                             o[2] = dyn_plus;

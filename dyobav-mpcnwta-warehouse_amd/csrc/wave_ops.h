@@ -186,7 +186,9 @@ template <typename T>
 __device__ __forceinline__ T wave_suffix_fix_rows(T x)
 {
     const T t1 = read_lane(x, 16), t2 = read_lane(x, 32), t3 = read_lane(x, 48);
-    const int row = (int)(threadIdx.x & 63) >> 4;
+    int l = (int)(threadIdx.x & 63);
+    asm volatile("" : "+v"(l)); // (opaque: keeps the three row masks from being hoisted into long-lived SGPR pairs)
+    const int row = l >> 4;
     const T s23 = t2 + t3, s123 = t1 + s23;
     const T add = row == 0 ? s123 : row == 1 ? s23 : row == 2 ? t3 : T(0);
     return x + add;

@@ -33,20 +33,20 @@ def test_config_struct_matches_header_defaults():
     assert cfg.tolerance == 1e-4 and cfg.initial_penalty == 10.0 and cfg.max_inner_iterations == 500
     assert cfg.max_outer_iterations == 10 and cfg.lbfgs_memory == 10
     assert cfg.latency_waves == 0 and cfg.akkt_form == 0 and cfg.max_solver_time_us == 0.0
-    assert cfg.coop_waves == 0 and cfg.lbfgs_gram == 0 and cfg.reg_table == 0 and cfg.reserved0 == 0
+    assert cfg.coop_waves == 0 and cfg.reserved1 == 0 and cfg.reg_table == 0 and cfg.reserved0 == 0
     # struct size and a late field's offset: ctypes mirror vs the C compiler on include/nmpc_hip.h (catches field drift)
     import subprocess, tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "sz.c")
         open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "nmpc_hip.h"\nint main(void){printf("%zu %zu %zu %zu", '
-                             'sizeof(nmpc_config), offsetof(nmpc_config, latency_waves), offsetof(nmpc_config, initial_penalty), offsetof(nmpc_config, lbfgs_gram));return 0;}\n')
+                             'sizeof(nmpc_config), offsetof(nmpc_config, latency_waves), offsetof(nmpc_config, initial_penalty), offsetof(nmpc_config, reg_table));return 0;}\n')
         exe = os.path.join(td, "sz")
         subprocess.run(["gcc", "-I", os.path.join(root, "include"), src, "-o", exe], check=True)
         size, off_lw, off_ip, off_gram = map(int, subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split())
     assert ctypes.sizeof(nm.NmpcConfigStruct) == size == 6 * 4 + 13 * 8 + 4 * 4 + 11 * 8 + 2 * 4 + 8 + 4 * 4
     assert nm.NmpcConfigStruct.latency_waves.offset == off_lw and nm.NmpcConfigStruct.initial_penalty.offset == off_ip
-    assert nm.NmpcConfigStruct.lbfgs_gram.offset == off_gram
+    assert nm.NmpcConfigStruct.reg_table.offset == off_gram
 
 
 def test_no_cpu_fallback_without_device():

@@ -65,7 +65,9 @@ def test_max_solver_time_budget_yields_out_of_time():
     L = nm.scenarios.ParamLayout()
     P = nm.scenarios.make_batch(64, L, seed=32)           # pedestrians walking at the robot: long solves
     pr = oracle.Problem()
-    with nm.Handle(config_for(pr)) as h:
+    # (a budget switches the cooperative kernel off -- every wavefront would read its own clock --, so the reference run
+    # of that mode is the throughput kernel it falls back to)
+    with nm.Handle(config_for(pr, coop_waves=1)) as h:
         ref = h.solve(P)
     with nm.Handle(config_for(pr, max_solver_time_us=200.0)) as h:      # 0.2 ms per solve
         short = h.solve(P)

@@ -1,0 +1,54 @@
+"""CPU test: register / spill figures of the kernels in the SHIPPED gfx950 code object (read from the AMDGPU metadata
+notes of the code object inside libnmpc_hip.so). Round 1 shipped 120-300 spilled SGPRs per solve kernel (v_writelane /
+v_readlane traffic on the critical path); the budgets below keep that from coming back."""
+import os
+import re
+import sys
+
+import pytest
+
+import dyobav_mpcnwta_warehouse_amd as nm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def resources():
+    import kernel_resources
+    nm.build_library()
+    res = {kernel_resources.short_name(k): v for k, v in kernel_resources.kernel_resources(nm.library_path()).items()}
+    assert len(res) >= 40
+    return res
+
+
+def _sel(res, pattern):
+    out = {k: v for k, v in res.items() if re.search(pattern, k)}
+    assert out, pattern
+    return out
+
+
+def test_fp32_throughput_kernels_do_not_spill(resources):
+    for name, r in _sel(resources, r"^solve_kernel<float").items():
+        assert r["sgpr_spill"] <= 16, (name, r)
+        assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (name, r)
+
+
+def test_register_budgets_of_the_kernel_variants(resources):
+    # residency follows from these: 2 / 3 wavefronts per SIMD for the 14- / 4-slot register table, 3 for the LDS table
+    assert resources["solve_kernel<float, 3, false, 14>"]["vgpr"] <= 256
+    assert resources["solve_kernel<float, 3, false, 4>"]["vgpr"] <= 168
+    assert resources["solve_kernel<float, 3, false, 0>"]["vgpr"] <= 168
+    for name, r in _sel(resources, r"^solve_spec_kernel<float.*, 0>").items():
+        assert r["vgpr"] <= 168 and r["vgpr_spill"] == 0, (name, r)
+
+
+def test_fp32_latency_and_cooperative_kernels_spill_little(resources):
+    for name, r in _sel(resources, r"^solve_(spec|coop)_kernel<float").items():
+        assert r["sgpr_spill"] <= 32, (name, r)
+        assert r["scratch"] <= 64, (name, r)
+
+
+def test_evaluation_and_data_kernels_are_spill_free(resources):
+    for name, r in _sel(resources, r"^(eval_kernel<float|void nmpc::(fill|hypotheses|select_static)_kernel)").items():
+        assert r["sgpr_spill"] == 0 and r["vgpr_spill"] == 0 and r["scratch"] == 0, (name, r)

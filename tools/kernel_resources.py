@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Register / spill / scratch figures of every kernel in the gfx950 code object (from the AMDGPU metadata that
-hipcc emits with -S). Used by tests/test_kernel_resources_cpu.py so that spills cannot creep back in unnoticed.
-   python tools/kernel_resources.py [extra hipcc flags...]"""
+"""Register / spill / scratch figures of every kernel in the gfx950 code object of the SHIPPED library (the AMDGPU
+metadata notes of the code object bundled in libnmpc_hip.so). tests/test_kernel_resources_cpu.py asserts on them so that
+spills cannot creep back in unnoticed.    python tools/kernel_resources.py [path/to/libnmpc_hip.so]"""
 import os
 import re
 import subprocess
@@ -9,7 +9,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "dyobav-mpcnwta-warehouse_amd", "csrc", "nmpc_capi.hip")
+DEFAULT_LIB = os.path.join(ROOT, "dyobav-mpcnwta-warehouse_amd", "libnmpc_hip.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
 
 
 def demangle(names):
@@ -20,30 +21,36 @@ def demangle(names):
         return list(names)
 
 
-def kernel_resources(extra_flags=()):
-    hipcc = "/opt/rocm/bin/hipcc"
+def kernel_resources(lib=DEFAULT_LIB):
     with tempfile.TemporaryDirectory() as td:
-        asm = os.path.join(td, "k.s")
-        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "--cuda-device-only", "-S",
-                        "-fno-slp-vectorize", "-Wno-unused-function", *extra_flags, "-o", asm, SRC], check=True, capture_output=True)
-        txt = open(asm).read()
-    meta = txt[txt.rfind("amdhsa.kernels"):]
-    rows = {}
-    names = []
-    for b in meta.split("\n  - ")[1:]:
+        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "gfx950.co")
+        subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
+        subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"], check=True,
+                       capture_output=True)
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True,
+                               text=True).stdout
+    meta = notes[notes.find("amdhsa.kernels"):]
+    rows, names = {}, []
+    for b in re.split(r"\n\s+- \.", meta)[1:]:
+        b = "." + b
         n = re.search(r"\.name:\s+(\S+)", b)
         if not n:
             continue
         g = lambda k: int((re.search(r"\.%s:\s+(\d+)" % k, b) or [None, "-1"])[1])
         names.append(n.group(1))
-        rows[n.group(1)] = dict(vgpr=g("vgpr_count"), agpr=g("agpr_count"), sgpr=g("sgpr_count"), vgpr_spill=g("vgpr_spill_count"),
-                                sgpr_spill=g("sgpr_spill_count"), scratch=g("private_segment_fixed_size"),
-                                lds_static=g("group_segment_fixed_size"))
+        rows[n.group(1)] = dict(vgpr=g("vgpr_count"), agpr=g("agpr_count"), sgpr=g("sgpr_count"),
+                                vgpr_spill=g("vgpr_spill_count"), sgpr_spill=g("sgpr_spill_count"),
+                                scratch=g("private_segment_fixed_size"), lds_static=g("group_segment_fixed_size"))
     return {d: rows[m] for m, d in zip(names, demangle(names))}
 
 
+def short_name(name):
+    name = re.sub(r"void \(anonymous namespace\)::", "", name)
+    return re.sub(r"\(nmpc::.*", "", name)
+
+
 if __name__ == "__main__":
-    for name, r in sorted(kernel_resources(sys.argv[1:]).items()):
-        short = re.sub(r"void \(anonymous namespace\)::", "", name)
-        short = re.sub(r"\(nmpc::.*", "", short)
-        print(f"{short:58s} vgpr {r['vgpr']:3d} agpr {r['agpr']:3d} sgpr {r['sgpr']:3d}  vgpr_spill {r['vgpr_spill']:3d}  sgpr_spill {r['sgpr_spill']:3d}  scratch {r['scratch']:4d} B")
+    for name, r in sorted(kernel_resources(*(sys.argv[1:2])).items()):
+        print(f"{short_name(name):58s} vgpr {r['vgpr']:3d} agpr {r['agpr']:3d} sgpr {r['sgpr']:3d}  vgpr_spill {r['vgpr_spill']:3d}"
+              f"  sgpr_spill {r['sgpr_spill']:3d}  scratch {r['scratch']:4d} B")
