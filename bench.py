@@ -291,6 +291,12 @@ def secondary_workloads(env: Env, args) -> list:
                     "unit": "solves/s", "ms_per_step": r["ms_per_step"], "steps": steps,
                     "batch": r["config"]["batch_per_gpu"], "kernel": r["roofline"]["kernel"],
                     "kernel_ms": r["roofline"]["kernel_ms"], "hbm_frac": r["roofline"]["frac"],
+                    # measured HBM-side traffic of this workload's committed PMC passes (profiles/rNN_*_traffic.json) over
+                    # this run's kernel time: the obstacle table of configs[4] is re-streamed on every evaluation, which
+                    # makes that configuration -- and only that one -- memory bound
+                    "traffic": r["roofline"]["traffic"],
+                    "traffic_GBps": (r["roofline"]["traffic"] / (r["roofline"]["kernel_ms"] * 1e-3) / 1e9
+                                     if r["roofline"]["traffic"] else None),
                     "valu_frac": r["roofline"]["valu"]["frac"], "converged_frac": r["solver"]["converged_frac"],
                     "converged_solves_per_s": r["solver"]["converged_solves_per_s"],
                     "inner_iters_mean": r["solver"]["inner_iters_mean"]})
@@ -320,7 +326,7 @@ def usable_cores() -> int:
 
 def probe_open() -> dict:
     """Is a genuine OpEn toolchain on this box (SURVEY.md 8c last row)? The reference's solver is
-    generated by opengen (Python) + casadi and compiled by cargo; with all three present `tools/opengen_problem.py`
+    generated by opengen (Python) + casadi and compiled by cargo; with all three present `tests/opengen_problem.py`
     builds the same problem with OpEn and the baseline below would be the real thing. Recorded either way."""
     import importlib.util
     import shutil
@@ -341,7 +347,7 @@ def cpu_baseline(layout, P_host):
     probe = probe_open()
     if probe["available"]:
         try:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
             import opengen_problem
             return opengen_problem.time_genuine_open(layout, P_host, cores, probe)
         except Exception as exc:   # an OpEn build that fails must not take the bench line with it
