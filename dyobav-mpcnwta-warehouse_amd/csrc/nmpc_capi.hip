@@ -82,6 +82,7 @@ struct Layout {
     int lds_xch, lds_total_spec; // latency mode: exchange area + the other wavefronts' parking areas behind lds_total
     int lds_park;
     int lds_xch_coop, lds_total_coop; // cooperative mode: kSpecWaves parking areas, then the partial-sum exchange area
+    int lds_left, lds_left_alpha;     // LDS table of the rows beyond the register-resident ones (cooperative register kernel)
     int dyn_cap;          // obstacle rows provisioned per instance
     int rs;               // > 0: register-resident obstacle table with this many slots per lane (LDS keeps t = 0 only)
     bool glb;             // obstacle table streamed from a global workspace instead of LDS
@@ -97,8 +98,14 @@ constexpr size_t kLdsLimit = 160 * 1024; // bytes of LDS one workgroup may use o
 int round4(int x) { return (x + 3) & ~3; }
 
 constexpr int kRegSlotsSmall = 4, kRegSlotsLarge = 14; // compiled register-table sizes (rows = 3 x slots)
+constexpr int kRegSlotsCoop = 12; // one lane per step: 8 cooperating wavefronts (2 per SIMD, 256 registers each) x 12 rows in
+                                  // registers; the rows beyond these 96 in LDS
+constexpr int kCoopRegWaves = 8;
 
-Layout make_layout(const nmpc_config& c, size_t elem_size)
+// coop_rs: layout of the cooperative register-table kernel (fp32, one lane per step): 4 x kRegSlotsCoop rows in the
+// registers of the four wavefronts, the t = 0 snapshot of all rows and the full table of the remaining rows in LDS --
+// nothing is streamed from global memory. L.rs = 0 on return if the configuration does not qualify.
+Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false)
 {
     Layout L;
     const int N = c.N_hor;
@@ -119,13 +126,23 @@ Layout make_layout(const nmpc_config& c, size_t elem_size)
         if (cap <= 3 * kRegSlotsSmall) L.rs = kRegSlotsSmall;
         else if (cap <= 3 * kRegSlotsLarge) L.rs = kRegSlotsLarge;
     }
+    int left_ne = 0; // entries of the LDS table of the rows beyond the register-resident ones (cooperative register kernel)
+    if (coop_rs) {
+        L.rs = 0;
+        if (elem_size == 4 && c.reg_table >= 0 && 64 / N == 1 && cap > 0) {
+            L.rs = kRegSlotsCoop;
+            left_ne = std::max(0, cap - kCoopRegWaves * kRegSlotsCoop) * (N + 1);
+        }
+    }
     const int ne = L.rs ? cap + 1 : cap * (N + 1); // table entries provisioned in LDS / the workspace (register table: t = 0 rows + the dummy)
     L.dyn_cap = cap;
     L.glb = false;
     L.ws_stride = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
     L.lds_alpha = L.glb ? 0 : nmpc::kEllStride * ne;
-    L.lds_poly = L.lds_alpha + (L.glb ? 0 : round4(ne));
+    L.lds_left = L.lds_alpha + (L.glb ? 0 : round4(ne));
+    L.lds_left_alpha = L.lds_left + nmpc::kEllStride * left_ne;
+    L.lds_poly = L.lds_left_alpha + round4(left_ne);
     L.lds_seg = L.lds_poly + 12 * c.Nstcobs;
     L.lds_seginv = L.lds_seg + 4 * N;
     L.lds_fl0 = L.lds_seginv + round4(N);
@@ -140,8 +157,13 @@ Layout make_layout(const nmpc_config& c, size_t elem_size)
     // 2 buffers x kSpecWaves x (64 lanes x 2 gradient entries + psi)
     L.lds_xch = L.lds_park + (L.rs ? kSpecWaves * park_one : 0);
     L.lds_total_spec = L.lds_xch + 2 * kSpecWaves * (2 * 64 + 4);
-    L.lds_xch_coop = L.lds_park + kSpecWaves * park_one;
-    L.lds_total_coop = L.lds_xch_coop + 2 * kSpecWaves * (3 * 64 + 4);
+    const int cw = coop_rs ? kCoopRegWaves : kSpecWaves;
+    L.lds_xch_coop = L.lds_park + cw * park_one;
+    L.lds_total_coop = L.lds_xch_coop + 2 * cw * (3 * 64 + 4);
+    if (coop_rs) { // no global fallback for this variant: it either fits LDS or is not offered
+        if ((size_t)L.lds_total_coop * elem_size > kLdsLimit) L.rs = 0;
+        break;
+    }
     if (L.glb || (size_t)L.lds_total * elem_size <= kLdsLimit) break;
     L.glb = true; // second attempt: everything but the ellipse table in LDS
     L.ws_stride = (long long)(nmpc::kEllStride + 1) * ne;
@@ -154,6 +176,7 @@ Layout make_layout(const nmpc_config& c, size_t elem_size)
 struct nmpc_handle_s {
     nmpc_config cfg;
     Layout lay32, lay64;
+    Layout lay32c; // cooperative register-table kernel (fp32, one lane per step); rs = 0 if not available
     int lps;
     int n_simd = 0; // SIMDs of the device (4 per CU): latency_waves = 0 picks the wavefront count from B / n_simd
     bool spec_ok[2] = {true, true}; // [f32, f64]
@@ -200,6 +223,13 @@ __global__ __launch_bounds__(64 * kSpecWaves, (sizeof(T) == 4 ? NMPC_SPEC_WPE_F3
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     nmpc::solve_instance<T, LPS, GLB, 0, true>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
+}
+// ... with the obstacle table on chip instead of in global memory, for one lane per horizon step (N > 32), where it does
+// not fit LDS: EIGHT wavefronts (two per SIMD) keep 12 rows each in registers, the remaining rows live in LDS
+__global__ __launch_bounds__(64 * kCoopRegWaves, 2) void solve_coop_reg_kernel(nmpc::KParams<float> kp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    nmpc::solve_instance<float, 1, false, kRegSlotsCoop, true>(kp, blockIdx.x, reinterpret_cast<float*>(smem));
 }
 
 // latency mode: kSpecWaves wavefronts per instance, speculative line search (nmpc_spec.h)
@@ -277,10 +307,10 @@ __global__ __launch_bounds__(64) void selftest_kernel(int* fails)
 }
 
 template <typename T>
-void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k)
+void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k, const Layout* layout = nullptr)
 {
     const nmpc_config& c = h->cfg;
-    const Layout& L = h->lay<T>();
+    const Layout& L = layout ? *layout : h->lay<T>();
     std::memset(&k, 0, sizeof k);
     k.N = c.N_hor;
     k.Nother = c.Nother;
@@ -308,6 +338,8 @@ void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k)
     k.lds_total = L.lds_total;
     k.lds_xch = L.lds_xch;
     k.lds_park = L.lds_park;
+    k.lds_left = L.lds_left;
+    k.lds_left_alpha = L.lds_left_alpha;
     k.ts = (T)c.ts;
     k.inv_ts = (T)(1.0 / c.ts);
     k.vmin = (T)c.lin_vel_min;
@@ -503,6 +535,23 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
         lds_bytes = (size_t)L.lds_total_coop * sizeof(T);
         k.lds_xch = L.lds_xch_coop;
         waves = coop;
+        if constexpr (sizeof(T) == 4) {
+            // the register-table variant is available (automatic / 4-wavefront request): eight wavefronts hold the table,
+            // nothing is streamed from global memory
+            if (coop == kSpecWaves && h->lay32c.rs > 0 && h->lps == 1) {
+                waves = kCoopRegWaves;
+                const Layout& C = h->lay32c;
+                const nmpc::KParams<T> keep = k;
+                fill_kparams(h, k, &C);
+                k.B = keep.B, k.P = keep.P, k.U = keep.U, k.cost = keep.cost, k.status = keep.status, k.iters = keep.iters;
+                k.u0 = keep.u0, k.y = keep.y, k.y_is_input = keep.y_is_input, k.c0v = keep.c0v, k.info = keep.info;
+                k.ws = nullptr;
+                k.ws_stride = 0;
+                k.lds_xch = C.lds_xch_coop;
+                fn = solve_coop_reg_kernel;
+                lds_bytes = (size_t)C.lds_total_coop * sizeof(T);
+            }
+        }
     }
     h->last_mode = coop > 1 ? 2 : waves ? 1 : 0;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
@@ -674,6 +723,12 @@ int set_lds_limit(nmpc_handle_s* h)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_eval<T>(h->lps, L.glb, L.rs)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
+    if (sizeof(T) == 4 && h->lay32c.rs > 0) {
+        const size_t cb = (size_t)h->lay32c.lds_total_coop * sizeof(float);
+        if (cb > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_coop_reg_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb));
+    }
     const size_t coop_bytes = (size_t)L.lds_total_coop * sizeof(T);
     if (coop_bytes > kLdsLimit) {
         h->coop_ok[sizeof(T) == 4 ? 0 : 1] = false;
@@ -786,6 +841,7 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
     h->cfg = *cfg;
     h->lay32 = make_layout(*cfg, sizeof(float));
     h->lay64 = make_layout(*cfg, sizeof(double));
+    h->lay32c = make_layout(*cfg, sizeof(float), true);
     h->lps = 64 / cfg->N_hor;
     if (h->lps > 3) h->lps = 3;
     if (h->lps < 1) h->lps = 1;
