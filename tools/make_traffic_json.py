@@ -15,7 +15,7 @@ def mean_counter(d, name):
     vals = []
     for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
         t = pd.read_csv(f)
-        t = t[t["Kernel_Name"].str.contains("solve_(?:spec_|coop_)?kernel", regex=True) & (t["Counter_Name"] == name)]
+        t = t[t["Kernel_Name"].str.contains("solve_\w*kernel", regex=True) & (t["Counter_Name"] == name)]
         if len(t):
             vals.append((t.groupby("Dispatch_Id")["Counter_Value"].sum().mean(), t["Kernel_Name"].iloc[0], t["Dispatch_Id"].nunique()))
     if not vals:
