@@ -43,7 +43,7 @@ WORKLOADS = {
              "cfg1_b1024_n20_2x5"),
     "cfg2": ("batch=65536 main_eva.py scenarios, mpc_fast.yaml N=20, 4 obs x 10 hypotheses, 1 MI355X",
              "cfg2_b65536_n20_4x10"),
-    "cfg4": ("long horizon N=40, 8 obs x 20 hypotheses, batch=8192, 1 MI355X (obstacle table streamed from HBM)",
+    "cfg4": ("long horizon N=40, 8 obs x 20 hypotheses, batch=8192, 1 MI355X",
              "cfg4_b8192_n40_8x20"),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
