@@ -174,10 +174,10 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         exchange = false;
     };
     // line-search candidates nls, nls+1, ... on wavefronts first, first+1, ... (tau is the candidate nls's step)
-    auto request_candidates = [&](int first) {
+    auto request_candidates = [&](int first, int wv) {
         exchange = true;
-        if (wave >= first) {
-            const int off = wave - first;
+        if (wv >= first) {
+            const int off = wv - first;
             T tw = tau;
             for (int i = 0; i < off; ++i) tw *= T(0.5);
             do_eval = nls + off <= MAX_LS; // candidate MAX_LS is accepted unconditionally, nothing lies beyond it
@@ -192,7 +192,12 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     // v_readfirstlane each) turns the state machine's control flow into scalar branches instead of lane-mask algebra.
     auto uni = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
     auto unib = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+    const int timed_ = __builtin_amdgcn_readfirstlane(time_budget > 0 ? 1 : 0);
     for (;;) {
+        // wavefront index / budget flag as opaque per-round values: conditions on them are then evaluated where they
+        // are used (s_cmp) instead of living in SGPR pairs as loop-invariant lane masks for the whole solve
+        int wv = wave, timed = timed_;
+        asm volatile("" : "+s"(wv), "+s"(timed));
         phase = uni(phase);
         iteration = uni(iteration);
         num_iter = uni(num_iter);
@@ -228,7 +233,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         NMPC_STAMP(I, 7); // (eval epilogue)
         const T* xr = xch + xbuf * (W * XS); // results of this round, one row per wavefront
         if (exchange) {
-            T* xw = xch + xbuf * (W * XS) + wave * XS;
+            T* xw = xch + xbuf * (W * XS) + wv * XS;
             if (do_eval) {
                 if (want_grad) {
                     xw[2 * I.lane] = r_gv;
@@ -236,13 +241,13 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 }
                 if (I.lane == 0) xw[2 * 64] = r_psi;
             }
-            if (time_budget > 0 && wave == 0 && I.lane == 0) {
+            if (timed && wv == 0 && I.lane == 0) {
                 long long el = (long long)__builtin_amdgcn_s_memrealtime() - t_start;
                 if (el > 0x7fffffffll) el = 0x7fffffffll;
                 *reinterpret_cast<int*>(xw + 2 * 64 + 1) = (int)el;
             }
             __syncthreads();
-            if (time_budget > 0)
+            if (timed)
                 t_now = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(xr + 2 * 64 + 1));
             xbuf ^= 1; // the next round writes the other buffer: no second barrier needed
             rounds++;
@@ -340,7 +345,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 if (process_candidates(1)) {
                     step_done = true;
                 } else {
-                    request_candidates(0);
+                    request_candidates(0, wv);
                     phase = SP_LSN;
                     continue;
                 }
@@ -360,7 +365,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             if (process_candidates(0)) {
                 step_done = true;
             } else {
-                request_candidates(0);
+                request_candidates(0, wv);
                 continue; // stay in SP_LSN
             }
         } else { // SP_OUTER
@@ -409,7 +414,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 if (!converged) status = out_of_time ? 2 : 1;
                 bool finite = tfinite(uv) && tfinite(uw) && tfinite(f_u);
                 if (__ballot(!finite) != 0ull) status = 3;
-                if (wave == 0) {
+                if (wv == 0) {
                     int ri = inst; // (opaque: result-row offsets computed here, not kept in SGPRs for the whole solve)
                     asm volatile("" : "+s"(ri));
                     if (lead) {
@@ -463,7 +468,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             } else {
                 num_iter++;
                 cont = num_iter < cold_args<T>()->max_inner;
-                if (time_budget > 0) cont_time = (long long)t_now <= time_budget;
+                if (timed) cont_time = (long long)t_now <= time_budget;
                 step_head = true;
             }
         }
@@ -564,8 +569,8 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         tau = 1;
         nls = 0;
         if (spec) {
-            request_candidates(1); // wavefronts 1.. : candidates 0..W-2
-            if (wave == 0) {       // wavefront 0: the Lipschitz test's psi(u_half)
+            request_candidates(1, wv); // wavefronts 1.. : candidates 0..W-2
+            if (wv == 0) {         // wavefront 0: the Lipschitz test's psi(u_half)
                 ev = hv;
                 ew = hw;
                 ec = c;
@@ -574,7 +579,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             }
             phase = SP_SPEC0;
         } else {
-            request_candidates(0);
+            request_candidates(0, wv);
             phase = SP_LSN;
         }
     }

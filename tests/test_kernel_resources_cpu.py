@@ -44,9 +44,11 @@ def test_register_budgets_of_the_kernel_variants(resources):
 
 
 def test_fp32_latency_and_cooperative_kernels_spill_little(resources):
-    for name, r in _sel(resources, r"^solve_(spec|coop)_kernel<float").items():
-        assert r["sgpr_spill"] <= 32, (name, r)
-        assert r["scratch"] <= 64, (name, r)
+    for name, r in _sel(resources, r"^solve_spec_kernel<float").items():
+        assert r["sgpr_spill"] <= 16, (name, r)
+        assert r["scratch"] <= 64, (name, r)            # (the register-table variants spill ~12 VGPRs; measured faster)
+    for name, r in _sel(resources, r"solve_coop(_reg)?_kernel(<float|$|\()").items():
+        assert r["sgpr_spill"] <= 24 and r["scratch"] == 0, (name, r)
 
 
 def test_evaluation_and_data_kernels_are_spill_free(resources):
