@@ -137,7 +137,10 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     };
 
     // cold solver vectors parked in LDS across the evaluation (see solve_instance); one area per wavefront
-    constexpr bool kSpecPark = RS > 0; // (the LDS-table variants fit their register budget without; measured)
+#ifndef NMPC_SPEC_PARK
+#define NMPC_SPEC_PARK 0
+#endif
+    constexpr bool kSpecPark = NMPC_SPEC_PARK && RS > 0; // (the LDS-table variants fit their register budget without; measured)
     Quad<T>* const parkp = reinterpret_cast<Quad<T>*>(lds + kp.lds_park) + wave * (kParkQuads * 64) + I.lane;
     auto park = [&]() {
         parkp[0 * 64] = Quad<T>{osv, osw, ogv, ogw};
@@ -224,10 +227,13 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         const T e_icd = ec == c ? inv_cdiv : T(1);
         if (do_eval) {
             if (kSpecPark) park();
+#ifndef NMPC_SPEC_FLAT
+#define NMPC_SPEC_FLAT 1
+#endif
             if (want_grad)
-                I.template eval<true>(ev, ew, ec, e_icd, yv, yw, r_psi, r_f2, r_gv, r_gw);
+                I.template eval<true, NMPC_SPEC_FLAT != 0>(ev, ew, ec, e_icd, yv, yw, r_psi, r_f2, r_gv, r_gw);
             else
-                I.template eval<false>(ev, ew, ec, e_icd, yv, yw, r_psi, r_f2, r_gv, r_gw);
+                I.template eval<false, NMPC_SPEC_FLAT != 0>(ev, ew, ec, e_icd, yv, yw, r_psi, r_f2, r_gv, r_gw);
             if (kSpecPark) unpark();
         }
         NMPC_STAMP(I, 7); // (eval epilogue)
