@@ -117,7 +117,7 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
     B = batch or spec.pop("B")
     spec.pop("B", None)
     spec["seed"] = spec["seed"] + env.rank           # every rank solves a different shard
-    P_host = nm.scenarios.make_batch(B, layout, ped_mode=family, **spec)
+    P_host = nm.scenarios.make_batch_chunked(B, layout, ped_mode=family, dtype=np_dtype, **spec)   # bounded host memory
     N = layout.N
 
     cfg = nm.default_config_struct()

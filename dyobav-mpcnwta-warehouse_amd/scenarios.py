@@ -203,6 +203,22 @@ BENCH_CONFIGS = {
 }
 
 
+def make_batch_chunked(B: int, layout: ParamLayout = ParamLayout(), seed: int = 0, chunk: int = 8192, dtype=np.float32,
+                       **kw) -> np.ndarray:
+    """``make_batch`` for large B with bounded host memory: the batch is generated ``chunk`` instances at a time (chunk
+    i from the seed sequence ``(seed, i)``) straight into the output array. Deterministic in (seed, B, chunk); for
+    B <= chunk it is ``make_batch(B, ..., seed=seed)`` itself. Used by bench.py, where eight ranks generate 65 536
+    instances each on one host (the float64 intermediates of one call would be ~8 GB per rank)."""
+    if B <= chunk:
+        return make_batch(B, layout, seed=seed, dtype=dtype, **kw)
+    out = np.empty((B, layout.np_), dtype=dtype)
+    for i, lo in enumerate(range(0, B, chunk)):
+        hi = min(B, lo + chunk)
+        sub = int(np.random.SeedSequence([seed, i]).generate_state(1)[0])
+        out[lo:hi] = make_batch(hi - lo, layout, seed=sub, dtype=dtype, **kw)
+    return out
+
+
 def make_config_batch(name: str, B: int | None = None, seed: int | None = None, dtype=np.float64):
     cfg = dict(BENCH_CONFIGS[name])
     if B is not None:
