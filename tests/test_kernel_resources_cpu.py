@@ -46,7 +46,7 @@ def test_register_budgets_of_the_kernel_variants(resources):
 def test_fp32_latency_and_cooperative_kernels_spill_little(resources):
     for name, r in _sel(resources, r"^solve_spec_kernel<float").items():
         assert r["sgpr_spill"] <= 16, (name, r)
-        assert r["scratch"] <= 64, (name, r)            # (the register-table variants spill ~12 VGPRs; measured faster)
+        assert r["scratch"] <= 96, (name, r)            # (the register-table variants spill ~20 VGPRs; measured faster)
     for name, r in _sel(resources, r"solve_coop(_reg)?_kernel(<float|$|\()").items():
         assert r["sgpr_spill"] <= 24 and r["scratch"] == 0, (name, r)
 
