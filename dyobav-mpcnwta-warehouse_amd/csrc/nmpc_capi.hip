@@ -666,13 +666,15 @@ int assemble_params(nmpc_handle_s* h, const nmpc_assemble_args* g, int32_t B, T*
     const size_t lds = (size_t)a.M * sizeof(T) + (size_t)a.Nstc * sizeof(int) + 16;
     if (lds > kLdsLimit) return fail(NMPC_ERR_UNSUPPORTED, "%d map polygons do not fit the selection kernel's LDS", a.M);
     // (every argument is validated before the first launch)
-    const unsigned per_block = 256u * nmpc::kFillPerLane, nchunk = ((unsigned)a.np + per_block - 1) / per_block;
-    if ((unsigned long long)B * nchunk >= (1ull << 31))
-        return fail(NMPC_ERR_UNSUPPORTED, "B = %d too large for one assembly call; split the batch", B);
+    // element pairs (8 / 16 B per lane) need every block boundary and every source row pair-aligned
+    const unsigned per = 6u * (a.N + 1);
+    const bool even = (a.np % 2 == 0) && (a.off_od % 2 == 0) && (a.off_qstc % 2 == 0) && (a.off_c0 % 2 == 0) &&
+                      (a.off_os % 2 == 0) && ((a.n_dyn * per) % 2 == 0);
+    const auto aligned = [](const void* q, size_t al) { return q == nullptr || reinterpret_cast<uintptr_t>(q) % al == 0; };
+    const unsigned vec_ok = even && aligned(a.P, 2 * sizeof(T)) && aligned(a.dyn, 2 * sizeof(T)) &&
+                            aligned(a.other_robots, 2 * sizeof(T));
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(nmpc::select_static_kernel<T>, dim3(B), dim3(64), lds, h->stream, a);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(nmpc::fill_kernel<T>, dim3((unsigned)B * nchunk), dim3(256), 0, h->stream, a, nchunk);
+    hipLaunchKernelGGL(nmpc::assemble_kernel<T>, dim3((unsigned)B), dim3(nmpc::kAsmThreads), lds, h->stream, a, vec_ok);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true;

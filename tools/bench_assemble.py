@@ -39,5 +39,5 @@ print(json.dumps({"metric": "parameter vectors assembled/sec (f1, device-side)",
                   "n_gpus": 1, "steps": steps, "dtype": "f32", "config": {"workload": f"B={B}, N=20, np={h.np_}, M={M} map polygons, {n_dyn} obstacles"},
                   "roofline": {"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                "frac": alg / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
-                               "kernel": "select_static_kernel + fill_kernel", "kernel_ms": k_ms,
+                               "kernel": "assemble_kernel (selection wavefront + byte-mover wavefronts, fused)", "kernel_ms": k_ms,
                                "algorithmic_bytes_per_launch": alg}}))
