@@ -707,7 +707,10 @@ int hypotheses_to_ellipses(nmpc_handle_s* h, const T* hypos, int32_t P, const T*
     a.dyn = dyn;
     a.n_obs = n_obs;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(nmpc::hypotheses_kernel<T>, dim3(B), dim3(64), 0, h->stream, a);
+    if (P <= 32)
+        hipLaunchKernelGGL((nmpc::hypotheses_kernel<T, unsigned>), dim3(B), dim3(64), 0, h->stream, a);
+    else
+        hipLaunchKernelGGL((nmpc::hypotheses_kernel<T, unsigned long long>), dim3(B), dim3(64), 0, h->stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true;

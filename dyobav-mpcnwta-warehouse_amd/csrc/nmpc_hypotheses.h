@@ -8,8 +8,14 @@
 //   main_base.py:293-302   obstacle list: row [mu_x, mu_y, std_x, std_y, 0, 1] per cluster and time offset, the current
 //                          positions with HUMAN_SIZE at offset 0, [0,0,0,0,0,1] where a used slot has no cluster
 //
-// One wavefront per instance, one lane per hypothesis point (P <= 64): the adjacency and reachability sets are 64-bit
-// lane masks, transitive closure by repeated squaring with v_readlane broadcasts, cluster statistics by DPP wave sums.
+// One wavefront per instance; a pass handles G = 64 / P time offsets at once, lane = g * P + i holding point i of offset
+// t0 + g (P = 20: three offsets per pass). The point coordinates of the pass are staged in LDS (one ds_read_b64 broadcasts
+// point j of the lane's own group), adjacency and reachability are P-bit masks relative to the group, the transitive
+// closure is Warshall's algorithm on the mask rows (P steps, row j fetched with ds_bpermute), and every lane sums the
+// statistics of ITS cluster over the group's points (centred on the cluster's first point, single pass) -- the first lane
+// of each cluster then stores the row. The kernel is instruction-issue bound: everything above is what keeps the count
+// per time offset at ~180 VALU/LDS instructions for P = 20 (the one-offset-per-pass version with v_readlane loops, closure
+// by repeated squaring and one wave-wide DPP reduction per cluster needed ~1500).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -28,76 +34,111 @@ struct HypParams {
     int* n_obs;     // [B] (may be null)
 };
 
-__device__ __forceinline__ unsigned long long read_lane_u64(unsigned long long v, int lane)
-{
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
-    return ((unsigned long long)hi << 32) | lo;
-}
 __device__ __forceinline__ float hsqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double hsqrt(double x) { return sqrt(x); }
 
-template <typename T>
+// value of v in lane (addr4 / 4) of the wavefront
+__device__ __forceinline__ unsigned bperm(unsigned v, int addr4) { return (unsigned)__builtin_amdgcn_ds_bpermute(addr4, (int)v); }
+__device__ __forceinline__ unsigned long long bperm(unsigned long long v, int addr4)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(addr4, (int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(addr4, (int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ int popc(unsigned v) { return __popc(v); }
+__device__ __forceinline__ int popc(unsigned long long v) { return __popcll(v); }
+__device__ __forceinline__ int ctz(unsigned v) { return (int)__builtin_ctz(v); }
+__device__ __forceinline__ int ctz(unsigned long long v) { return (int)__builtin_ctzll(v); }
+
+// M: mask type of one group (unsigned for P <= 32, unsigned long long for P <= 64)
+template <typename T, typename M>
 __global__ __launch_bounds__(64) void hypotheses_kernel(HypParams<T> a)
 {
     __shared__ int counts[65]; // clusters per time offset (index 0 = current positions)
+    __shared__ T pts[64 * 2];  // (x, y) of the pass, by lane
     const int b = blockIdx.x, lane = threadIdx.x & 63;
-    const int NP1 = a.N + 1;
+    const int NP1 = a.N + 1, P = a.P;
+    const int G = 64 / P;              // time offsets per pass
+    const int g = lane / P, i = lane - g * P;
+    const bool in_group = g < G;
+    const int gbase = in_group ? g * P : 0;
+    const M one = 1;
+    const M all = P == (int)(8 * sizeof(M)) ? ~M(0) : (one << P) - one;
     T* out = a.dyn + (size_t)b * a.Ndyn * NP1 * 6;
-    const bool on = lane < a.P;
-    int max_cl = a.H;
+    const T eps2 = a.eps * a.eps;
     if (lane == 0) counts[0] = a.H;
-    for (int t = 0; t < a.N; ++t) {
-        const T* pt = a.hypos + (((size_t)b * a.N + t) * a.P + (on ? lane : 0)) * 2;
-        const T x = on ? pt[0] : T(0), y = on ? pt[1] : T(0);
-        // adjacency: bit j of adj = point j within eps of this lane's point (incl. itself)
-        unsigned long long adj = 0;
-        const T eps2 = a.eps * a.eps;
-        for (int j = 0; j < a.P; ++j) {
-            const T dx = x - read_lane(x, j), dy = y - read_lane(y, j);
-            if (dx * dx + dy * dy <= eps2) adj |= 1ull << j;
+    for (int t0 = 0; t0 < a.N; t0 += G) {
+        const int t = t0 + g;
+        const bool on = in_group && t < a.N;
+        const T* pt = a.hypos + (((size_t)b * a.N + (on ? t : 0)) * P + i) * 2;
+        T x = 0, y = 0;
+        if (on) {
+            x = pt[0];
+            y = pt[1];
+        }
+        __syncthreads(); // (one wavefront: orders the LDS reads of the previous pass before these writes)
+        pts[2 * lane] = x;
+        pts[2 * lane + 1] = y;
+        __syncthreads();
+        const T* gp = pts + 2 * gbase;
+        // adjacency: bit j = point j of this group within eps of this lane's point (incl. itself)
+        M adj = 0;
+#pragma clang loop vectorize(disable) unroll_count(4)
+        for (int j = 0; j < P; ++j) {
+            const T dx = x - gp[2 * j], dy = y - gp[2 * j + 1];
+            if (dx * dx + dy * dy <= eps2) adj |= one << j;
         }
         if (!on) adj = 0;
-        const bool noise = __popcll(adj) < 2; // min_samples = 2 counts the point itself
-        // transitive closure: reach <- reach o reach, 6 squarings cover paths of length 64
-        unsigned long long reach = adj;
-        for (int it = 0; it < 6; ++it) {
-            unsigned long long nw = reach;
-            for (int j = 0; j < a.P; ++j) {
-                const unsigned long long rj = read_lane_u64(reach, j);
-                if ((reach >> j) & 1ull) nw |= rj;
-            }
-            const bool changed = __ballot(nw != reach) != 0ull;
-            reach = nw;
-            if (!changed) break;
+        const bool noise = popc(adj) < 2; // min_samples = 2 counts the point itself
+        // transitive closure (Warshall): after step j every row holds the points reachable through points 0..j
+        M reach = adj;
+        const int ga4 = gbase * 4;
+#pragma clang loop vectorize(disable) unroll_count(4)
+        for (int j = 0; j < P; ++j) {
+            const M rj = bperm(reach, ga4 + 4 * j);
+            if ((reach >> j) & one) reach |= rj;
         }
-        const int label = noise ? 64 : (int)__builtin_ctzll(reach); // smallest index of the component
-        const unsigned long long leaders = __ballot(!noise && label == lane);
-        const int ncl = __popcll(leaders);
-        const int cid = noise ? -1 : __popcll(leaders & ((1ull << label) - 1ull));
-        if (lane == 0) counts[t + 1] = ncl;
-        max_cl = ncl > max_cl ? ncl : max_cl;
-        const int nstore = ncl < a.Ndyn ? ncl : a.Ndyn;
-        for (int c = 0; c < nstore; ++c) { // wave-uniform
-            const bool in = cid == c;
-            T cnt, sx, sy;
-            wave_sum3(in ? T(1) : T(0), in ? x : T(0), in ? y : T(0), cnt, sx, sy);
-            const T mx = sx / cnt, my = sy / cnt;
-            T vx, vy;
-            wave_sum2(in ? (x - mx) * (x - mx) : T(0), in ? (y - my) * (y - my) : T(0), vx, vy);
-            if (lane == 0) {
-                T* o = out + ((size_t)c * NP1 + (t + 1)) * 6;
-                o[0] = mx;
-                o[1] = my;
-                o[2] = hsqrt(vx / cnt) * a.enlarge + a.extra_margin;
-                o[3] = hsqrt(vy / cnt) * a.enlarge + a.extra_margin;
-                o[4] = T(0);
-                o[5] = T(1);
-            }
+        const int label = noise ? 0 : ctz(reach); // smallest index of the component
+        const bool leader = !noise && label == i;
+        const M leaders = (M)(__ballot(leader) >> gbase) & all;
+        const int ncl = popc(leaders);
+        const int cid = popc(leaders & ((one << label) - one));
+        if (on && i == 0) counts[t + 1] = ncl;
+        // statistics of this lane's cluster, centred on its first point
+        const T xr = gp[2 * label], yr = gp[2 * label + 1];
+        T cnt = 0, sx = 0, sy = 0, sxx = 0, syy = 0;
+#pragma clang loop vectorize(disable) unroll_count(4)
+        for (int j = 0; j < P; ++j) {
+            const bool in = (reach >> j) & one;
+            const T dx = in ? gp[2 * j] - xr : T(0), dy = in ? gp[2 * j + 1] - yr : T(0);
+            cnt += in ? T(1) : T(0);
+            sx += dx;
+            sy += dy;
+            sxx += dx * dx;
+            syy += dy * dy;
+        }
+        if (leader && cid < a.Ndyn) {
+            const T inv = T(1) / cnt;
+            const T mx = sx * inv, my = sy * inv;
+            const T vx = sxx * inv - mx * mx, vy = syy * inv - my * my;
+            T* o = out + ((size_t)cid * NP1 + (t + 1)) * 6;
+            o[0] = xr + mx;
+            o[1] = yr + my;
+            o[2] = hsqrt(vx > T(0) ? vx : T(0)) * a.enlarge + a.extra_margin;
+            o[3] = hsqrt(vy > T(0) ? vy : T(0)) * a.enlarge + a.extra_margin;
+            o[4] = T(0);
+            o[5] = T(1);
         }
     }
     __syncthreads();
-    const int n_obs = max_cl; // main_base.py:294-297
+    int max_cl = a.H; // main_base.py:294-297
+    for (int t = lane; t < a.N; t += 64) max_cl = counts[t + 1] > max_cl ? counts[t + 1] : max_cl;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const int o = __shfl_xor(max_cl, s);
+        max_cl = o > max_cl ? o : max_cl;
+    }
+    const int n_obs = max_cl;
     const int used = n_obs < a.Ndyn ? n_obs : a.Ndyn;
     if (lane == 0 && a.n_obs) a.n_obs[b] = n_obs;
     // offset 0: current positions; empty slots of used obstacles: [0,0,0,0,0,1]; unused obstacles: zeros

@@ -92,3 +92,35 @@ def test_edge_cases_single_points_and_overflow():
         assert nobs[0] == 20 and (dyn[0, :, 1:, 5] == 1).all()
         with pytest.raises(nm.NmpcError):
             _run(h, np.float64, np.zeros((1, 20, 65, 2)), np.zeros((1, 1, 2)))
+
+
+@pytest.mark.parametrize("P", [1, 2, 7, 20, 21, 32, 33, 40, 64])
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_point_counts_and_chain_clusters(P, dt):
+    """Every lane grouping of the kernel (64 // P time offsets per pass, 32- and 64-bit masks) against the numpy oracle;
+    half of the instances are chains (neighbours 0.9 eps apart in shuffled order: the component is only found through
+    paths as long as the point count), the rest blobs with noise points."""
+    rng = np.random.default_rng(100 + P)
+    B, N = 24, 20
+    hypos = np.empty((B, N, P, 2))
+    for b in range(B):
+        for t in range(N):
+            if b % 2 == 0:
+                n1 = int(rng.integers(1, P + 1))
+                chain = np.c_[np.arange(n1) * 0.9, np.zeros(n1)] + rng.uniform(-3, 3, 2)
+                rest = rng.uniform(20, 60, (P - n1, 2))
+                pts = np.r_[chain, rest]
+            else:
+                ctr = rng.uniform(-6, 6, (3, 2))
+                pts = ctr[rng.integers(0, 3, P)] + rng.normal(0, 0.3, (P, 2))
+            hypos[b, t] = pts[rng.permutation(P)]
+    cur = rng.uniform(-4, 4, (B, 2, 2))
+    if dt == np.float32:  # the oracle sees the same rounded inputs
+        hypos, cur = hypos.astype(np.float32).astype(np.float64), cur.astype(np.float32).astype(np.float64)
+    tol = 1e-11 if dt == np.float64 else 2e-4
+    with nm.Handle(config_for(oracle.Problem())) as h:
+        dyn, nobs = _run(h, dt, hypos, cur)
+    for b in range(B):
+        want, n = oh.hypotheses_to_obstacles(cur[b], hypos[b])
+        assert nobs[b] == n
+        np.testing.assert_allclose(dyn[b], want, rtol=0, atol=tol)
