@@ -81,7 +81,7 @@ struct Layout {
     int lds_alpha, lds_poly, lds_seg, lds_seginv, lds_fl0, lds_fl, lds_iflag, lds_hist, lds_rho, lds_total;
     int lds_xch, lds_total_spec; // latency mode: exchange area + the other wavefronts' parking areas behind lds_total
     int lds_park;
-    int lds_xch_coop, lds_total_coop; // cooperative mode: kSpecWaves parking areas, then the partial-sum exchange area
+    int lds_xch_coop, lds_total_coop; // cooperative mode: two shared parking areas, then the partial-sum exchange area
     int lds_left, lds_left_alpha;     // LDS table of the rows beyond the register-resident ones (cooperative register kernel)
     int dyn_cap;          // obstacle rows provisioned per instance
     int rs;               // > 0: register-resident obstacle table with this many slots per lane (LDS keeps t = 0 only)
@@ -158,8 +158,8 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false)
     L.lds_xch = L.lds_park + (L.rs ? kSpecWaves * park_one : 0);
     L.lds_total_spec = L.lds_xch + 2 * kSpecWaves * (2 * 64 + 4);
     const int cw = coop_rs ? kCoopRegWaves : kSpecWaves;
-    L.lds_xch_coop = L.lds_park + cw * park_one;
-    L.lds_total_coop = L.lds_xch_coop + 2 * cw * (3 * 64 + 4);
+    L.lds_xch_coop = L.lds_park + 2 * park_one; // cooperative kernels: two shared parking areas, used alternately
+    L.lds_total_coop = L.lds_xch_coop + 2 * cw * nmpc::kCoopXchStride;
     if (coop_rs) { // no global fallback for this variant: it either fits LDS or is not offered
         if ((size_t)L.lds_total_coop * elem_size > kLdsLimit) L.rs = 0;
         break;

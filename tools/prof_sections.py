@@ -12,7 +12,7 @@ wl = sys.argv[2] if len(sys.argv) > 2 else "cfg1"
 key = {"cfg1": "cfg1_b1024_n20_2x5", "cfg2": "cfg2_b65536_n20_4x10", "cfg4": "cfg4_b8192_n40_8x20"}[wl]
 L, P = nm.scenarios.make_config_batch(key, B=B)
 spec = nm.scenarios.BENCH_CONFIGS[key]
-cfg = nm.default_config_struct(); cfg.lbfgs_memory = int(os.environ.get("LBFGS_MEM", "10")); cfg.latency_waves = 1
+cfg = nm.default_config_struct(); cfg.lbfgs_memory = int(os.environ.get("LBFGS_MEM", "10")); cfg.latency_waves = int(os.environ.get("LW", "1"))
 cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs = L.N, L.Nother, L.Nstc, L.Ndyn
 cfg.max_active_dynobs = spec["n_ped"] * spec["n_hyp"]
 h = nm.Handle(cfg)
