@@ -101,6 +101,10 @@ constexpr int kRegSlotsSmall = 4, kRegSlotsLarge = 14; // compiled register-tabl
 constexpr int kRegSlotsCoop = 12; // one lane per step: 8 cooperating wavefronts (2 per SIMD, 256 registers each) x 12 rows in
                                   // registers; the rows beyond these 96 in LDS
 constexpr int kCoopRegWaves = 8;
+// Horizons of 33..42 steps leave 22..31 lanes of every wavefront without a step: there the kernel is compiled with helper
+// lanes (nmpc_device.h, HLP) that take a third row in each pass of two slots -- 8 x 18 = 144 rows in registers.
+bool coop_helper_lanes(int N) { return N >= 33 && N <= 42; }
+int coop_reg_rows(int N) { return kCoopRegWaves * (coop_helper_lanes(N) ? 3 * (kRegSlotsCoop / 2) : kRegSlotsCoop); }
 
 // coop_rs: layout of the cooperative register-table kernel (fp32, one lane per step): 4 x kRegSlotsCoop rows in the
 // registers of the four wavefronts, the t = 0 snapshot of all rows and the full table of the remaining rows in LDS --
@@ -131,7 +135,7 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false)
         L.rs = 0;
         if (elem_size == 4 && c.reg_table >= 0 && 64 / N == 1 && cap > 0) {
             L.rs = kRegSlotsCoop;
-            left_ne = std::max(0, cap - kCoopRegWaves * kRegSlotsCoop) * (N + 1);
+            left_ne = std::max(0, cap - coop_reg_rows(N)) * (N + 1);
         }
     }
     const int ne = L.rs ? cap + 1 : cap * (N + 1); // table entries provisioned in LDS / the workspace (register table: t = 0 rows + the dummy)
@@ -226,10 +230,11 @@ __global__ __launch_bounds__(64 * kSpecWaves, (sizeof(T) == 4 ? NMPC_SPEC_WPE_F3
 }
 // ... with the obstacle table on chip instead of in global memory, for one lane per horizon step (N > 32), where it does
 // not fit LDS: EIGHT wavefronts (two per SIMD) keep 12 rows each in registers, the remaining rows live in LDS
+template <bool HLP>
 __global__ __launch_bounds__(64 * kCoopRegWaves, 2) void solve_coop_reg_kernel(nmpc::KParams<float> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    nmpc::solve_instance<float, 1, false, kRegSlotsCoop, true>(kp, blockIdx.x, reinterpret_cast<float*>(smem));
+    nmpc::solve_instance<float, 1, false, kRegSlotsCoop, true, HLP>(kp, blockIdx.x, reinterpret_cast<float*>(smem));
 }
 
 // latency mode: kSpecWaves wavefronts per instance, speculative line search (nmpc_spec.h)
@@ -371,12 +376,59 @@ void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k, const Layout* lay
     k.time_budget = c.max_solver_time_us > 0 ? (long long)(c.max_solver_time_us * 100.0 + 0.5) : 0; // 100 MHz ticks
 }
 
+// The same evaluation through the cooperative kernels' code path (W wavefronts share it; wavefront 0 writes): what
+// nmpc_eval_batch_* launches when the handle's coop_waves asks for the cooperative mode, so that psi / grad psi of the
+// row split, the partial-sum exchange and the helper lanes can be compared with the oracle directly.
+template <typename T, int LPS, bool GLB, int RS, bool HLP, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (RS > 0 ? 2 : (sizeof(T) == 4 ? NMPC_SPEC_WPE_F32 : NMPC_WPE_F64)))
+void eval_coop_kernel(nmpc::KParams<T> kp, nmpc::EvalParams<T> ep)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int inst = blockIdx.x, N = kp.N;
+    T* lds = reinterpret_cast<T*>(smem);
+    nmpc::Instance<T, LPS, GLB, RS, true, HLP> I(kp, kp.P + (size_t)inst * kp.np, lds,
+                                                 GLB ? kp.ws + (long long)inst * kp.ws_stride : nullptr);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    I.cw_ = wave;
+    I.CW_ = (int)(blockDim.x >> 6);
+    I.coop_x = lds + kp.lds_xch;
+    if (!I.load()) {
+        if (threadIdx.x == 0) ep.psi[inst] = __builtin_nanf("");
+        return;
+    }
+    const int kk = I.act ? I.k : 0;
+    T v = ep.U[(size_t)inst * 2 * N + 2 * kk], w = ep.U[(size_t)inst * 2 * N + 2 * kk + 1];
+    T yv = ep.Y[(size_t)inst * 2 * N + kk], yw = ep.Y[(size_t)inst * 2 * N + N + kk];
+    if (!I.act) v = w = yv = yw = 0;
+    const T c = ep.C[inst];
+    const T icd = T(1) / (c > T(1) ? c : T(1));
+    T psi, f2, gv, gw;
+    if (ep.grad)
+        I.template eval<true>(v, w, c, icd, yv, yw, psi, f2, gv, gw);
+    else
+        I.template eval<false>(v, w, c, icd, yv, yw, psi, f2, gv, gw);
+    if (wave != 0) return;
+    if (I.lead && ep.grad) {
+        ep.grad[(size_t)inst * 2 * N + 2 * I.k] = gv;
+        ep.grad[(size_t)inst * 2 * N + 2 * I.k + 1] = gw;
+    }
+    if (I.lane == 0) {
+        ep.psi[inst] = psi;
+        if (ep.f2sq) ep.f2sq[inst] = f2;
+    }
+}
+
 template <typename T>
 using SolveFn = void (*)(nmpc::KParams<T>);
 template <typename T>
 using EvalFn = void (*)(nmpc::KParams<T>, nmpc::EvalParams<T>);
 
 // the register-table variants exist for float with three lanes per step only
+void (*pick_solve_coop_reg(int N))(nmpc::KParams<float>)
+{
+    return coop_helper_lanes(N) ? solve_coop_reg_kernel<true> : solve_coop_reg_kernel<false>;
+}
+
 template <typename T>
 SolveFn<T> pick_solve(int lps, bool glb, int rs = 0)
 {
@@ -414,6 +466,19 @@ EvalFn<T> pick_eval(int lps, bool glb, int rs = 0)
     }
     if (glb) return lps == 3 ? eval_kernel<T, 3, true> : lps == 2 ? eval_kernel<T, 2, true> : eval_kernel<T, 1, true>;
     return lps == 3 ? eval_kernel<T, 3, false> : lps == 2 ? eval_kernel<T, 2, false> : eval_kernel<T, 1, false>;
+}
+
+template <typename T>
+EvalFn<T> pick_eval_coop(int lps, bool glb)
+{
+    constexpr int W = kSpecWaves;
+    if (glb) return lps == 3 ? eval_coop_kernel<T, 3, true, 0, false, W> : lps == 2 ? eval_coop_kernel<T, 2, true, 0, false, W> : eval_coop_kernel<T, 1, true, 0, false, W>;
+    return lps == 3 ? eval_coop_kernel<T, 3, false, 0, false, W> : lps == 2 ? eval_coop_kernel<T, 2, false, 0, false, W> : eval_coop_kernel<T, 1, false, 0, false, W>;
+}
+EvalFn<float> pick_eval_coop_reg(int N)
+{
+    return coop_helper_lanes(N) ? eval_coop_kernel<float, 1, false, kRegSlotsCoop, true, kCoopRegWaves>
+                                : eval_coop_kernel<float, 1, false, kRegSlotsCoop, false, kCoopRegWaves>;
 }
 
 // stage `count` elements: returns the device pointer to use (src itself if already on the device)
@@ -548,7 +613,7 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
                 k.ws = nullptr;
                 k.ws_stride = 0;
                 k.lds_xch = C.lds_xch_coop;
-                fn = solve_coop_reg_kernel;
+                fn = pick_solve_coop_reg(h->cfg.N_hor);
                 lds_bytes = (size_t)C.lds_total_coop * sizeof(T);
             }
         }
@@ -602,9 +667,31 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
     if ((rc = stage_out(h, h->dpsi, psi, (size_t)B, &ep.psi, &hpsi))) return rc;
     if ((rc = stage_out(h, h->dgrad, grad, (size_t)B * n, &ep.grad, &hgrad))) return rc;
     if ((rc = stage_out(h, h->df2, f2sq, (size_t)B, &ep.f2sq, &hf2))) return rc;
-    const size_t lds_bytes = (size_t)L.lds_total * sizeof(T);
+    size_t lds_bytes = (size_t)L.lds_total * sizeof(T);
     EvalFn<T> fn = pick_eval<T>(h->lps, L.glb, L.rs);
-    hipLaunchKernelGGL(fn, dim3(B), dim3(64), lds_bytes, h->stream, k, ep);
+    int waves = 1;
+    // coop_waves > 1: evaluate through the cooperative kernels' code path (same variant choice as solve_batch)
+    if (h->cfg.coop_waves > 1 && L.rs == 0 && h->coop_ok[sizeof(T) == 4 ? 0 : 1]) {
+        waves = std::min<int>(h->cfg.coop_waves, kSpecWaves);
+        fn = pick_eval_coop<T>(h->lps, L.glb);
+        lds_bytes = (size_t)L.lds_total_coop * sizeof(T);
+        k.lds_xch = L.lds_xch_coop;
+        if constexpr (sizeof(T) == 4) {
+            if (waves == kSpecWaves && h->lay32c.rs > 0 && h->lps == 1) {
+                const Layout& C = h->lay32c;
+                const nmpc::KParams<T> keep = k;
+                fill_kparams(h, k, &C);
+                k.B = keep.B, k.P = keep.P;
+                k.ws = nullptr;
+                k.ws_stride = 0;
+                k.lds_xch = C.lds_xch_coop;
+                waves = kCoopRegWaves;
+                fn = pick_eval_coop_reg(h->cfg.N_hor);
+                lds_bytes = (size_t)C.lds_total_coop * sizeof(T);
+            }
+        }
+    }
+    hipLaunchKernelGGL(fn, dim3(B), dim3(64 * waves), lds_bytes, h->stream, k, ep);
     HIP_TRY(hipGetLastError());
     if (hpsi) HIP_TRY(hipMemcpyAsync(psi, ep.psi, (size_t)B * sizeof(T), hipMemcpyDeviceToHost, h->stream));
     if (hgrad) HIP_TRY(hipMemcpyAsync(grad, ep.grad, (size_t)B * n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
@@ -731,7 +818,10 @@ int set_lds_limit(nmpc_handle_s* h)
     if (sizeof(T) == 4 && h->lay32c.rs > 0) {
         const size_t cb = (size_t)h->lay32c.lds_total_coop * sizeof(float);
         if (cb > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_coop_reg_kernel),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve_coop_reg(h->cfg.N_hor)),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb));
+        if (cb > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_eval_coop_reg(h->cfg.N_hor)),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb));
     }
     const size_t coop_bytes = (size_t)L.lds_total_coop * sizeof(T);
@@ -739,6 +829,8 @@ int set_lds_limit(nmpc_handle_s* h)
         h->coop_ok[sizeof(T) == 4 ? 0 : 1] = false;
     } else if (coop_bytes > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve_coop<T>(h->lps, L.glb)),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_eval_coop<T>(h->lps, L.glb)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_bytes));
     }
     const size_t spec_bytes = (size_t)L.lds_total_spec * sizeof(T);

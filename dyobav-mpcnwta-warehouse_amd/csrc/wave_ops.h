@@ -41,6 +41,19 @@ __device__ __forceinline__ double dpp_mov(double old, double x)
     return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
+// value of x in lane addr4 / 4 (ds_bpermute_b32: any lane pattern, through the LDS crossbar, no memory touched)
+__device__ __forceinline__ float bperm(float x, int addr4)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr4, __builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ double bperm(double x, int addr4)
+{
+    const unsigned long long v = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(addr4, (int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(addr4, (int)(unsigned)(v >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ float read_lane(float x, int lane)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));

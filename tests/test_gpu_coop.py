@@ -101,3 +101,68 @@ def test_cooperative_full_solves_and_automatic_choice():
     with nm.Handle(cfg) as h:
         r = h.solve(P4)
     assert (r["info"][:, 7] >= 0).all()
+
+
+def _obstacles_on_the_path(N, Ndyn, rows, B, seed):
+    """Parameter vectors whose ``rows`` non-zero obstacle slots (scattered over the Ndyn slots) sit ON the robot's
+    reference path, so that hard ellipses are violated along the horizon."""
+    lay = ParamLayout(N=N, Ndyn=Ndyn)
+    P = nm.scenarios.make_batch(B, lay, seed=seed, n_ped=0, n_hyp=1, ped_mode="oncoming")
+    rng = np.random.default_rng(1000 * N + rows)
+    od = np.zeros((B, Ndyn, N + 1, 6))
+    s0 = P[:, lay.s0:lay.s0 + 3]
+    ref = P[:, lay.rs:lay.rs + 3 * N].reshape(B, N, 3)
+    slots = rng.permutation(Ndyn)[:rows]
+    for b in range(B):
+        path = np.r_[s0[b:b + 1, :2], ref[b, :, :2]]
+        for j in slots:
+            ctr = path[rng.integers(0, N)] + rng.normal(0, 0.15, 2)
+            od[b, j, :, 0:2] = ctr + np.arange(N + 1)[:, None] * rng.normal(0, 0.02, 2)
+            od[b, j, :, 2:4] = rng.uniform(0.3, 0.8, 2)
+            od[b, j, :, 4] = rng.uniform(-1.5, 1.5)
+            od[b, j, :, 5] = rng.uniform(0.2, 1.0, N + 1)
+    P[:, lay.od:lay.od + od[0].size] = od.reshape(B, -1)
+    return lay, P
+
+
+@pytest.mark.parametrize("N", [33, 40, 42, 43])
+@pytest.mark.parametrize("rows", [1, 2, 3, 4, 17, 143, 144, 145, 160])
+def test_on_chip_kernel_psi_and_gradient_match_oracle(N, rows):
+    """psi, grad psi and ||F2||^2 evaluated THROUGH the on-chip cooperative kernel's code path (nmpc_eval_batch with
+    coop_waves = 4: eight wavefronts, register + LDS table) against the fp64 oracle. Horizons of 33..42 steps use the
+    helper lanes (the lanes behind the horizon take a third obstacle row per pass: 144 rows in registers), 43 is the
+    first horizon without them (96 rows). Obstacles sit on the path so that the hard ellipses are violated -- the E_j sums
+    of the helper rows and their gradient factors are exercised -- with row counts around every boundary of the
+    row -> (wavefront, pass, slot) map; the controls follow the reference path roughly, multipliers and penalties random."""
+    import oracle
+    Ndyn, B = 160, 6
+    lay, P = _obstacles_on_the_path(N, Ndyn, rows, B, seed=70 + N)
+    pr = oracle.Problem(N, 10, 10, Ndyn)
+    rng = np.random.default_rng(7 * N + rows)
+    U = np.stack([rng.uniform(0.6, 1.4, (B, N)), rng.uniform(-0.15, 0.15, (B, N))], axis=2).reshape(B, 2 * N)
+    Y = rng.normal(size=(B, 2 * N))
+    C = rng.uniform(1, 100, B)
+    P32 = P.astype(np.float32)
+    cfg = nm.default_config_struct()
+    cfg.N_hor, cfg.Ndynobs = N, Ndyn
+    cfg.latency_waves, cfg.coop_waves, cfg.reg_table = 1, 4, 0
+    with nm.Handle(cfg) as h:
+        r = h.eval(P32, U, Y, C, dtype=np.float32)
+        again = h.eval(P32, U, Y, C, dtype=np.float32)
+    cfg.coop_waves, cfg.reg_table = 1, -1
+    with nm.Handle(cfg) as h:
+        one = h.eval(P32, U, Y, C, dtype=np.float32)       # one wavefront, global-memory table
+    assert np.array_equal(r["grad"], again["grad"]) and np.array_equal(r["psi"], again["psi"])
+    violated = 0
+    for i in range(B):
+        u, y, c = U[i].astype(np.float32).astype(np.float64), Y[i].astype(np.float32).astype(np.float64), float(np.float32(C[i]))
+        v, g = oracle.psi(pr, u, c, y, P32[i].astype(np.float64))
+        f2 = oracle.eval_problem(pr, u, P32[i].astype(np.float64))[2]
+        violated += bool((np.asarray(f2) > 0).any())
+        assert r["psi"][i] == pytest.approx(v, rel=1e-4)
+        np.testing.assert_allclose(r["grad"][i], g, rtol=0, atol=1e-3 * np.abs(g).max())
+        assert r["f2sq"][i] == pytest.approx(float(np.sum(np.asarray(f2) ** 2)), rel=2e-3, abs=1e-6)
+    assert violated >= B // 2 or rows < 3                  # the hard-ellipse terms are really in play
+    # and as close to the one-wavefront kernel as fp32 summation order allows
+    np.testing.assert_allclose(r["psi"], one["psi"], rtol=2e-5)
+    np.testing.assert_allclose(r["grad"], one["grad"], rtol=0, atol=2e-4 * np.abs(one["grad"]).max())
