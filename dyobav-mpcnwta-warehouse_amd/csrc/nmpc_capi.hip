@@ -98,8 +98,8 @@ constexpr size_t kLdsLimit = 160 * 1024; // bytes of LDS one workgroup may use o
 int round4(int x) { return (x + 3) & ~3; }
 
 constexpr int kRegSlotsSmall = 4, kRegSlotsLarge = 14; // compiled register-table sizes (rows = 3 x slots)
-constexpr int kRegSlotsCoop = 12; // one lane per step: 8 cooperating wavefronts (2 per SIMD, 256 registers each) x 12 rows in
-                                  // registers; the rows beyond these 96 in LDS
+constexpr int kRegSlotsCoop = 12; // one lane per step: 8 cooperating wavefronts (2 per SIMD, 256 registers each) x 12 slots in
+                                  // registers (96 rows; 144 with helper lanes, below); the rows beyond those in LDS
 constexpr int kCoopRegWaves = 8;
 // Horizons of 33..42 steps leave 22..31 lanes of every wavefront without a step: there the kernel is compiled with helper
 // lanes (nmpc_device.h, HLP) that take a third row in each pass of two slots -- 8 x 18 = 144 rows in registers.
