@@ -126,7 +126,7 @@ def _obstacles_on_the_path(N, Ndyn, rows, B, seed):
 
 
 @pytest.mark.parametrize("N", [33, 40, 42, 43])
-@pytest.mark.parametrize("rows", [1, 2, 3, 4, 17, 143, 144, 145, 160])
+@pytest.mark.parametrize("rows", [0, 1, 2, 3, 4, 17, 143, 144, 145, 160])
 def test_on_chip_kernel_psi_and_gradient_match_oracle(N, rows):
     """psi, grad psi and ||F2||^2 evaluated THROUGH the on-chip cooperative kernel's code path (nmpc_eval_batch with
     coop_waves = 4: eight wavefronts, register + LDS table) against the fp64 oracle. Horizons of 33..42 steps use the
