@@ -774,7 +774,8 @@ int hypotheses_to_ellipses(nmpc_handle_s* h, const T* hypos, int32_t P, const T*
 {
     if (!h || !hypos || !cur || !dyn) return fail(NMPC_ERR_INVALID_ARGUMENT, "null argument");
     if (B <= 0) return B == 0 ? 0 : fail(NMPC_ERR_INVALID_ARGUMENT, "B = %d < 0", B);
-    if (P < 1 || P > 64) return fail(NMPC_ERR_UNSUPPORTED, "P = %d hypothesis points per time offset outside [1, 64]", P);
+    if (P < 1 || P > 256) return fail(NMPC_ERR_UNSUPPORTED, "P = %d hypothesis points per time offset outside [1, 256]", P);
+    if (h->cfg.N_hor > 64) return fail(NMPC_ERR_UNSUPPORTED, "nmpc_hypotheses_to_ellipses: N_hor = %d > 64", h->cfg.N_hor);
     if (H < 0 || H > h->cfg.Ndynobs) return fail(NMPC_ERR_INVALID_ARGUMENT, "H = %d outside [0, Ndynobs]", H);
     if (!is_device_ptr(hypos) || !is_device_ptr(cur) || !is_device_ptr(dyn) || (n_obs && !is_device_ptr(n_obs)))
         return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_hypotheses_to_ellipses: every array must be a device pointer");
@@ -796,8 +797,14 @@ int hypotheses_to_ellipses(nmpc_handle_s* h, const T* hypos, int32_t P, const T*
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     if (P <= 32)
         hipLaunchKernelGGL((nmpc::hypotheses_kernel<T, unsigned>), dim3(B), dim3(64), 0, h->stream, a);
-    else
+    else if (P <= 64)
         hipLaunchKernelGGL((nmpc::hypotheses_kernel<T, unsigned long long>), dim3(B), dim3(64), 0, h->stream, a);
+    else if (P <= 128)
+        hipLaunchKernelGGL((nmpc::hypotheses_wide_kernel<T, 2>), dim3(B), dim3(64), 0, h->stream, a);
+    else if (P <= 192)
+        hipLaunchKernelGGL((nmpc::hypotheses_wide_kernel<T, 3>), dim3(B), dim3(64), 0, h->stream, a);
+    else
+        hipLaunchKernelGGL((nmpc::hypotheses_wide_kernel<T, 4>), dim3(B), dim3(64), 0, h->stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true;

@@ -91,13 +91,15 @@ def test_edge_cases_single_points_and_overflow():
         dyn, nobs = _run(h, np.float64, pairs, np.array([[[0.0, 0.0]]]))
         assert nobs[0] == 20 and (dyn[0, :, 1:, 5] == 1).all()
         with pytest.raises(nm.NmpcError):
-            _run(h, np.float64, np.zeros((1, 20, 65, 2)), np.zeros((1, 1, 2)))
+            _run(h, np.float64, np.zeros((1, 20, 257, 2)), np.zeros((1, 1, 2)))
 
 
-@pytest.mark.parametrize("P", [1, 2, 7, 20, 21, 32, 33, 40, 64])
+@pytest.mark.parametrize("P", [1, 2, 7, 20, 21, 32, 33, 40, 64, 65, 100, 128, 129, 160, 192, 193, 256])
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 def test_point_counts_and_chain_clusters(P, dt):
-    """Every lane grouping of the kernel (64 // P time offsets per pass, 32- and 64-bit masks) against the numpy oracle;
+    """Every lane grouping of the kernels (64 // P time offsets per pass, 32- and 64-bit masks; above 64 points the wide
+    kernel with 2, 3 or 4 points per lane -- 160 = the 8 pedestrians x 20 hypotheses of BASELINE configs[4], which the
+    reference clusters together, main_base.py:192-196) against the numpy oracle;
     half of the instances are chains (neighbours 0.9 eps apart in shuffled order: the component is only found through
     paths as long as the point count), the rest blobs with noise points."""
     rng = np.random.default_rng(100 + P)
