@@ -40,3 +40,33 @@ def test_accuracy_protocol(workload, family, n):
     else:                                      # contract family: almost nothing converges; the runs must still agree
         assert abs(row["converged_frac"]["hip64"] - row["converged_frac"]["oracle64"]) <= 0.1
         assert np.isfinite(a["median_abs_du_all"])
+
+
+def test_tight_solutions_match_an_independent_nlp_solver():
+    """The solver-independent check of tests/test_fixed_point_independent.py on the device: controls of the HIP kernels
+    at tightened tolerance against scipy SLSQP on the reference's problem (obstacle-free family, zero initial guess on
+    both sides). fp64 at 1e-8 must meet the north star's max|u - u_ref| < 1e-4; fp32 is run at 1e-5 (near its rounding
+    floor) against a stated tolerance of 1e-3; every solver kernel."""
+    import test_fixed_point_independent as fpi
+    P = nm.scenarios.make_batch(12, fpi.LAY, seed=33, n_ped=0, n_boxes=0)
+    ref = np.array([fpi._slsqp(p)[0] for p in P])
+    # fp32: measured 2e-4 median / 5e-4 worst converged instance at tolerance 1e-5 -- its stated tolerance is 1e-3
+    for dtype, tol, bound, med in ((np.float64, 1e-8, 1e-4, 5e-6), (np.float32, 1e-5, 1e-3, 5e-4)):
+        for name, ov in (("throughput", dict(latency_waves=1, coop_waves=1)), ("latency", dict(latency_waves=4)),
+                         ("cooperative", dict(latency_waves=1, coop_waves=4, reg_table=-1))):
+            cfg = nm.default_config_struct()
+            cfg.tolerance = cfg.initial_tolerance = cfg.delta_tolerance = tol
+            cfg.max_outer_iterations, cfg.max_inner_iterations = 12, 3000
+            cfg.lip_eps_f64 = cfg.lip_delta_f64 = 1e-6
+            for k, v in ov.items():
+                setattr(cfg, k, v)
+            with nm.Handle(cfg) as h:
+                r = h.solve(P.astype(dtype), dtype=dtype)
+            du = np.abs(r["U"].astype(np.float64) - ref).max(axis=1)
+            conv = r["status"] == 0
+            print(f"{np.dtype(dtype).name} {name}: {conv.sum()}/12 converged, max|u - u_slsqp| median {np.median(du):.2e}, "
+                  f"max over converged {du[conv].max():.2e}, max over all {du.max():.2e}")
+            # (the instances that run into the outer-iteration cap -- active acceleration bounds, penalty escalation --
+            #  stop wherever 12 x 3000 iterations took them: within ~1e-2)
+            assert conv.sum() >= 9 and du[conv].max() < bound and np.median(du) < med, (dtype, name, du)
+            assert dtype == np.float32 or du.max() < 2e-2, (dtype, name, du)   # (fp32: such an instance is flagged, not pinned)
