@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Randomised differential check of the f1 kernel (device-side parameter assembly; run by hand on the GPU box, not
+collected by pytest): random dimensions (N, Nother, Nstcobs, Ndynobs), map sizes (0 .. 200 polygons: fewer than slots,
+one per lane, selection rounds), numbers of obstacle rows, with and without the fleet block, fp64 and fp32, against
+oracle/assemble.py -- every element of P, including the nearest-first order of the chosen polygons.
+    python tests/fuzz_assemble.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dyobav_mpcnwta_warehouse_amd as nm   # noqa: E402
+from oracle import assemble as oa           # noqa: E402
+from dyobav_mpcnwta_warehouse_amd.scenarios import ParamLayout  # noqa: E402
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    checked, worst = 0, 0.0
+    for ci in range(cases):
+        N, Nother = int(rng.integers(2, 65)), int(rng.integers(1, 13))
+        Nstc, Ndyn = int(rng.integers(1, 15)), int(rng.integers(1, 60))
+        M = int(rng.choice([0, 1, Nstc - 1, Nstc, Nstc + 1, 63, 64, 65, rng.integers(0, 200)]))
+        M = max(M, 0)
+        n_dyn = int(rng.integers(0, Ndyn + 1))
+        B = int(rng.choice([1, 3, 64, 257]))
+        lay = ParamLayout(N=N, Nother=Nother, Nstc=Nstc, Ndyn=Ndyn)
+        state = np.c_[rng.uniform(-6, 6, (B, 2)), rng.uniform(-3, 3, B)]
+        last_u = rng.uniform(-1, 1, (B, 2))
+        refs = rng.uniform(-8, 8, (B, N, 3))
+        speed = rng.uniform(0.5, 1.5, B)
+        tuning, stcw, dynw = rng.uniform(0, 100, 10), rng.uniform(0, 20, N), rng.uniform(0, 20, N)
+        ctr, half, ang = rng.uniform(-8, 8, (M, 2)), rng.uniform(0.3, 1.2, (M, 2)), rng.uniform(-np.pi, np.pi, M)
+        corners = np.array([[1, 1], [-1, 1], [-1, -1], [1, -1]])[None] * half[:, None, :]
+        R = np.stack([np.stack([np.cos(ang), -np.sin(ang)], 1), np.stack([np.sin(ang), np.cos(ang)], 1)], 1)
+        polys = np.einsum("mvi,mji->mvj", corners, R) + ctr[:, None, :]
+        dyn = rng.uniform(-6, 6, (B, n_dyn, N + 1, 6)) if n_dyn else None
+        other = rng.normal(size=(B, 3 * (N + 1) * Nother)) if rng.random() < 0.5 else None
+        cfg = nm.default_config_struct()
+        cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs = N, Nother, Nstc, Ndyn
+        for dt, tol in ((np.float64, 1e-12), (np.float32, 2e-6)):
+            tdt = torch.float64 if dt == np.float64 else torch.float32
+            dev = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x, dtype=dt)).cuda()
+            with nm.Handle(cfg) as h:
+                assert h.np_ == lay.np_
+                P = torch.full((B, h.np_), float("nan"), dtype=tdt, device="cuda")
+                h.assemble_params(dt, B, P, dev(last_u), dev(state), dev(refs), dev(speed), dev(tuning), dev(stcw), dev(dynw),
+                                  dev(polys) if M else None, dev(dyn), dev(other))
+                torch.cuda.synchronize()
+            P = P.cpu().numpy().astype(np.float64)
+            for b in sorted(set([0, B - 1, int(rng.integers(0, B))])):
+                c = lambda x: np.asarray(x, dtype=dt).astype(np.float64)       # the oracle sees the rounded inputs
+                want = oa.assemble(c(last_u[b]), c(state[b]), c(refs[b]), float(c(speed[b])), c(tuning),
+                                   None if other is None else c(other[b]), list(c(polys)), None if dyn is None else c(dyn[b]),
+                                   c(stcw), c(dynw), N=N, Nother=Nother, Nstc=Nstc, Ndyn=Ndyn)
+                err = np.abs(P[b] - want) / np.maximum(1.0, np.abs(want))
+                checked += 1
+                worst = max(worst, float(np.nanmax(err)))
+                if np.isnan(P[b]).any() or not (err < max(tol, 1e-9 if dt == np.float64 else 2e-3)).all():
+                    k = int(np.nanargmax(np.where(np.isnan(P[b]), np.inf, err)))
+                    print(f"MISMATCH case {ci}: N={N} Nother={Nother} Nstc={Nstc} Ndyn={Ndyn} M={M} n_dyn={n_dyn} B={B} "
+                          f"dtype={np.dtype(dt).name} instance {b} element {k} (o_s block {lay.os}..{lay.od}): {P[b][k]} vs {want[k]}")
+                    return 1
+    print(f"{cases} cases, {checked} parameter vectors checked element by element; worst relative error {worst:.2e}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
