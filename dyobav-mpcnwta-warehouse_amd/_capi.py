@@ -58,6 +58,7 @@ class NmpcAssembleArgs(C.Structure):
 # every symbol include/nmpc_hip.h declares (checked by the CPU test-suite against the built library)
 EXPORTED_SYMBOLS = (
     "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_param_len", "nmpc_set_stream", "nmpc_use_own_stream", "nmpc_set_pointer_mode",
+    "nmpc_set_dispatch_order",
     "nmpc_solve_batch_f32", "nmpc_solve_batch_f64", "nmpc_eval_batch_f32", "nmpc_eval_batch_f64",
     "nmpc_assemble_params_f32", "nmpc_assemble_params_f64",
     "nmpc_hypotheses_to_ellipses_f32", "nmpc_hypotheses_to_ellipses_f64",
@@ -194,6 +195,19 @@ class Handle:
     def set_pointer_mode(self, mode: int):
         """0 = classify every array argument per call (default), 1 = all host pointers, 2 = all device pointers."""
         _check(self._lib.nmpc_set_pointer_mode(self._h, int(mode)))
+
+    def set_dispatch_order(self, order=None):
+        """Workgroup b of the following solves of ``len(order)`` instances takes instance ``order[b]`` (a permutation:
+        numpy int32 array, or an int32 device tensor on the handle's stream; e.g. ``np.argsort(-previous_evals)`` =
+        longest first). The library copies it. ``None`` clears it."""
+        if order is None:
+            _check(self._lib.nmpc_set_dispatch_order(self._h, None, 0))
+        elif isinstance(order, np.ndarray) or not hasattr(order, "data_ptr"):
+            a = np.ascontiguousarray(order, dtype=np.int32)
+            _check(self._lib.nmpc_set_dispatch_order(self._h, C.c_void_p(a.ctypes.data), int(a.size)))
+        else:
+            assert str(order.dtype) == "torch.int32" and order.is_contiguous()
+            _check(self._lib.nmpc_set_dispatch_order(self._h, C.c_void_p(order.data_ptr()), int(order.numel())))
 
     def selftest(self) -> int:
         return _check(self._lib.nmpc_selftest(self._h))

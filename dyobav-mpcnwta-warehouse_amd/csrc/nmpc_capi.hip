@@ -197,6 +197,8 @@ struct nmpc_handle_s {
     bool timed = false;
     int ptr_mode = NMPC_PTR_DETECT;
     DevBuf dP, dU, dcost, dstatus, diters, du0, dy, dc0, dinfo, dY2, dC2, dpsi, dgrad, df2, dws;
+    DevBuf dorder;   // dispatch order of the next solves (nmpc_set_dispatch_order), order_B entries; 0 = none
+    int order_B = 0;
 };
 
 namespace {
@@ -218,7 +220,7 @@ template <typename T, int LPS, bool GLB, int RS = 0>
 __global__ __launch_bounds__(64, (wpe<T, RS>(NMPC_WPE_F32))) void solve_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    nmpc::solve_instance<T, LPS, GLB, RS>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
+    nmpc::solve_instance<T, LPS, GLB, RS>(kp, nmpc::dispatch_index(kp), reinterpret_cast<T*>(smem));
 }
 
 // cooperative mode: up to kSpecWaves wavefronts per instance share every evaluation (nmpc_device.h, COOP)
@@ -226,7 +228,7 @@ template <typename T, int LPS, bool GLB>
 __global__ __launch_bounds__(64 * kSpecWaves, (sizeof(T) == 4 ? NMPC_SPEC_WPE_F32 : NMPC_WPE_F64)) void solve_coop_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    nmpc::solve_instance<T, LPS, GLB, 0, true>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
+    nmpc::solve_instance<T, LPS, GLB, 0, true>(kp, nmpc::dispatch_index(kp), reinterpret_cast<T*>(smem));
 }
 // ... with the obstacle table on chip instead of in global memory, for one lane per horizon step (N > 32), where it does
 // not fit LDS: EIGHT wavefronts (two per SIMD) keep 12 rows each in registers, the remaining rows live in LDS
@@ -234,7 +236,7 @@ template <bool HLP>
 __global__ __launch_bounds__(64 * kCoopRegWaves, 2) void solve_coop_reg_kernel(nmpc::KParams<float> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    nmpc::solve_instance<float, 1, false, kRegSlotsCoop, true, HLP>(kp, blockIdx.x, reinterpret_cast<float*>(smem));
+    nmpc::solve_instance<float, 1, false, kRegSlotsCoop, true, HLP>(kp, nmpc::dispatch_index(kp), reinterpret_cast<float*>(smem));
 }
 
 // latency mode: kSpecWaves wavefronts per instance, speculative line search (nmpc_spec.h)
@@ -242,7 +244,7 @@ template <typename T, int LPS, bool GLB, int RS = 0>
 __global__ __launch_bounds__(64 * kSpecWaves, (wpe<T, RS>(NMPC_SPEC_WPE_F32))) void solve_spec_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    nmpc::solve_instance_spec<T, LPS, GLB, RS>(kp, blockIdx.x, reinterpret_cast<T*>(smem));
+    nmpc::solve_instance_spec<T, LPS, GLB, RS>(kp, nmpc::dispatch_index(kp), reinterpret_cast<T*>(smem));
 }
 
 template <typename T, int LPS, bool GLB, int RS = 0>
@@ -618,6 +620,7 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
             }
         }
     }
+    k.order = h->order_B == B ? static_cast<const int*>(h->dorder.p) : nullptr;
     h->last_mode = coop > 1 ? 2 : waves ? 1 : 0;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(fn, dim3(B), dim3(waves ? 64 * waves : 64), lds_bytes, h->stream, k);
@@ -1012,6 +1015,33 @@ int nmpc_set_pointer_mode(nmpc_handle h, int32_t mode)
     if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
     if (mode < NMPC_PTR_DETECT || mode > NMPC_PTR_DEVICE) return fail(NMPC_ERR_INVALID_ARGUMENT, "pointer mode %d", mode);
     h->ptr_mode = mode;
+    return 0;
+}
+
+int nmpc_set_dispatch_order(nmpc_handle h, const int32_t* order, int32_t B)
+{
+    if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (!order || B <= 0) {
+        h->order_B = 0;
+        return 0;
+    }
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    if (int rc = h->dorder.reserve((size_t)B * sizeof(int32_t))) return rc;
+    if (is_device_ptr(order)) {
+        // (a device-resident order is taken as it is: it must be a permutation of 0..B-1)
+        HIP_TRY(hipMemcpyAsync(h->dorder.p, order, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        std::vector<unsigned char> seen((size_t)B, 0);
+        for (int32_t i = 0; i < B; ++i) {
+            const int32_t v = order[i];
+            if (v < 0 || v >= B || seen[(size_t)v])
+                return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_set_dispatch_order: order[%d] = %d: not a permutation of 0..%d", i, v, B - 1);
+            seen[(size_t)v] = 1;
+        }
+        HIP_TRY(hipMemcpyAsync(h->dorder.p, order, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream)); // (the host array may be released by the caller on return)
+    }
+    h->order_B = B;
     return 0;
 }
 

@@ -421,7 +421,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 bool finite = tfinite(uv) && tfinite(uw) && tfinite(f_u);
                 if (__ballot(!finite) != 0ull) status = 3;
                 if (wv == 0) {
-                    int ri = inst; // (opaque: result-row offsets computed here, not kept in SGPRs for the whole solve)
+                    int ri = inst;
                     asm volatile("" : "+s"(ri));
                     if (lead) {
                         kc->U[(size_t)ri * 2 * N + 2 * I.k] = uv;

@@ -145,6 +145,10 @@ class BatchEvaluator:
         self.P = torch.empty(B, self.h.np_, dtype=self.tdt, device=self.dev)
         self.U = torch.empty(B, 2 * self.N, dtype=self.tdt, device=self.dev)
         self._Ua = torch.empty(B, 2 * self.N, dtype=self.tdt, device=self.dev)   # compacted batch of the running scenarios
+        # dispatch order of a time step's solves from the evaluation counts of the previous one (nmpc_set_dispatch_order)
+        self.dispatch_by_history, self.dispatch_min_batch = True, 32768   # (measured: -4 % at 16 384 scenarios, +10 % at 65 536)
+        self._info = torch.zeros(B, 8, dtype=self.tdt, device=self.dev)
+        self._evals = torch.zeros(B, dtype=self.tdt, device=self.dev)
         self.y = torch.zeros(B, 2 * self.N, dtype=self.tdt, device=self.dev)
         self.status = torch.empty(B, dtype=torch.int32, device=self.dev)
 
@@ -277,7 +281,21 @@ class BatchEvaluator:
             u0 = None
             if self.warm_start and kt > 0:
                 u0 = sel(torch.cat([self.U[:, 2:], self.U[:, -2:]], dim=1))
-            self.h.solve_raw(self.dt, Pa, nA, Ua, u0=u0, y=ya, y_is_input=kt > 0, sync=False)
+            # longest first: the evaluation counts of the previous time step rank this step's solves (a scenario that
+            # was hard a moment ago still is); pure scheduling -- the results do not depend on the order
+            if self.dispatch_by_history and nA >= self.dispatch_min_batch:
+                if kt > 0:
+                    prev = self._evals if full else self._evals.index_select(0, idx)
+                    self.h.set_dispatch_order(torch.argsort(prev, descending=True, stable=True).to(torch.int32))
+                info = self._info[:nA]
+            else:
+                info = None
+            self.h.solve_raw(self.dt, Pa, nA, Ua, u0=u0, y=ya, y_is_input=kt > 0, info=info, sync=False)
+            if info is not None:
+                if full:
+                    self._evals.copy_(info[:, 4])
+                else:
+                    self._evals.index_copy_(0, idx, info[:, 4].contiguous())
             if not full:
                 self.U.index_copy_(0, idx, Ua)
                 self.y.index_copy_(0, idx, ya)

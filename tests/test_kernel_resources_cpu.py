@@ -50,7 +50,7 @@ def test_fp32_latency_and_cooperative_kernels_spill_little(resources):
     for name, r in _sel(resources, r"solve_coop(_reg)?_kernel(<float|$|\()").items():
         # (SGPR -> VGPR-lane spills only, no scratch; the segment chunk bounds and the exchange of the partial minima
         # added ~8 to the on-chip kernel in exchange for the 24 % they bought on configs[4])
-        assert r["sgpr_spill"] <= 32 and r["scratch"] == 0, (name, r)
+        assert r["sgpr_spill"] <= 36 and r["scratch"] == 0, (name, r)
 
 
 def test_evaluation_and_data_kernels_are_spill_free(resources):

@@ -26,6 +26,8 @@ cfg = nm.default_config_struct()
 cfg.max_active_dynobs = 2
 BatchEvaluator(cfg, starts[:64], paths[:64], hstart[:64], hpath[:64], np.array(boxes), dtype=dtype).run(max_steps=3)  # warm-up
 ev = BatchEvaluator(cfg, starts, paths, hstart, hpath, np.array(boxes), dtype=dtype, human_stagger=0.2, seed=5)
+if os.environ.get("DISPATCH") == "index":      # (diagnostic: switch the history-based dispatch order off)
+    ev.dispatch_by_history = False
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 res = ev.run(max_steps=max_steps)
@@ -39,5 +41,6 @@ print(json.dumps({
     "lockstep_steps": len(res.solve_ms), "scenario_steps": scen_steps,
     "solve_kernel_ms_total": float(np.sum(res.solve_ms)), "solve_kernel_share": float(np.sum(res.solve_ms)) * 1e-3 / el,
     "solve_kernel_ms_per_step": [round(float(x), 2) for x in res.solve_ms[:6]] + ["..."] + [round(float(x), 2) for x in res.solve_ms[-3:]],
+    "dispatch": "longest first by the previous time step's evaluation counts" if ev.dispatch_by_history and B >= ev.dispatch_min_batch else "index order",
     "complete_rate": float(res.complete.mean()), "collision_rate": float((res.collision & ~res.complete).mean()),
     "mean_steps": float(res.steps.mean())}))

@@ -12,7 +12,8 @@ spec = nm.scenarios.BENCH_CONFIGS[key]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else spec["B"]
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 dt = np.float64 if os.environ.get("DT") == "f64" else np.float32
-L, P = nm.scenarios.make_config_batch(key, B=B, dtype=dt)
+spec2 = dict(spec); lay = spec2.pop("layout"); spec2.pop("B")
+L, P = lay, nm.scenarios.make_batch_chunked(B, lay, ped_mode=os.environ.get("FAMILY", "toward_robot"), dtype=dt, **spec2)
 cfg = nm.default_config_struct()
 cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs = L.N, L.Nother, L.Nstc, L.Ndyn
 cfg.max_active_dynobs = spec["n_ped"] * spec["n_hyp"]
@@ -24,5 +25,12 @@ ms = []
 for _ in range(reps + 1):
     h.solve_raw(dt, P, B, U, status=st, iters=it)
     ms.append(h.last_kernel_ms())
+if os.environ.get("ORDER") == "lpt":   # longest first, by the evaluation counts of the pass above
+    info = np.empty((B, 8), dt); h.solve_raw(dt, P, B, U, status=st, iters=it, info=info)
+    h.set_dispatch_order(np.argsort(-info[:, 4], kind="stable").astype(np.int32))
+    ms = []
+    for _ in range(reps + 1):
+        h.solve_raw(dt, P, B, U, status=st, iters=it)
+        ms.append(h.last_kernel_ms())
 k = float(np.mean(ms[1:]))
 print(f"{wl} B={B} {dt.__name__}: kernel {k:.1f} ms -> {B / k * 1e3:.0f} solves/s; inner iters mean {it[:, 1].mean():.0f}; converged {np.mean(st == 0):.4f}; U checksum {float(np.abs(U).sum()):.6f}")
