@@ -108,6 +108,22 @@ class BatchEvaluator:
             self.cfg = config
         self.h = _capi.Handle(config)
         self.h.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        # Within the latency-kernel family the number of wavefronts per instance does not change the result (the W
+        # candidates of a round are evaluated with the same arithmetic as one after the other; bit-identical for W = 2,
+        # 3, 4 -- tests/test_gpu_options.py), so W follows the number of scenarios still running: as many wavefronts per
+        # instance as stay resident together. One handle per W.
+        self._h_by_waves = {}
+        if config.latency_waves >= 2:
+            import copy
+            self._n_simd = 4 * torch.cuda.get_device_properties(self.dev).multi_processor_count
+            for w in (2, 3, 4):
+                if w == config.latency_waves:
+                    self._h_by_waves[w] = self.h
+                else:
+                    c = copy.copy(config)
+                    c.latency_waves = w
+                    self._h_by_waves[w] = _capi.Handle(c)
+                    self._h_by_waves[w].set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
         self.N, self.ts = config.N_hor, config.ts
         B = self.B = robot_starts.shape[0]
         T = lambda x, dt=None: torch.as_tensor(np.ascontiguousarray(x), dtype=dt or self.tdt, device=self.dev)
@@ -283,14 +299,18 @@ class BatchEvaluator:
                 u0 = sel(torch.cat([self.U[:, 2:], self.U[:, -2:]], dim=1))
             # longest first: the evaluation counts of the previous time step rank this step's solves (a scenario that
             # was hard a moment ago still is); pure scheduling -- the results do not depend on the order
+            hs = self.h
+            if self._h_by_waves:      # latency-kernel family: W by the size of the running batch (results unchanged)
+                cap = 3 * self._n_simd if self.dt == np.float32 else 2 * self._n_simd     # resident wavefronts
+                hs = self._h_by_waves[min(4, max(2, cap // max(nA, 1)))]
             if self.dispatch_by_history and nA >= self.dispatch_min_batch:
                 if kt > 0:
                     prev = self._evals if full else self._evals.index_select(0, idx)
-                    self.h.set_dispatch_order(torch.argsort(prev, descending=True, stable=True).to(torch.int32))
+                    hs.set_dispatch_order(torch.argsort(prev, descending=True, stable=True).to(torch.int32))
                 info = self._info[:nA]
             else:
                 info = None
-            self.h.solve_raw(self.dt, Pa, nA, Ua, u0=u0, y=ya, y_is_input=kt > 0, info=info, sync=False)
+            hs.solve_raw(self.dt, Pa, nA, Ua, u0=u0, y=ya, y_is_input=kt > 0, info=info, sync=False)
             if info is not None:
                 if full:
                     self._evals.copy_(info[:, 4])
@@ -303,7 +323,7 @@ class BatchEvaluator:
                 Pfull = self.P if full else torch.zeros_like(self.P).index_copy_(0, idx, Pa)
                 rec.update(P=Pfull.cpu().numpy(), U=self.U.cpu().numpy())
                 record.append(rec)
-            solve_ms.append(self.h.last_kernel_ms())
+            solve_ms.append(hs.last_kernel_ms())
             raw = self.U[:, :2].clone()
             act = torch.where((raw[:, 0:1] < 0), torch.zeros_like(raw), raw)     # no-backward, main_base.py:320-321
             new_robot = unicycle_rk4_step(self.robot, act, ts)
@@ -337,4 +357,5 @@ class BatchEvaluator:
             trajectory=torch.stack(traj, dim=1).cpu().numpy(), actions=A.cpu().numpy(), solve_ms=solve_ms)
 
     def close(self):
-        self.h.close()
+        for h in set(self._h_by_waves.values()) | {self.h}:
+            h.close()

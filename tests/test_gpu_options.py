@@ -120,3 +120,28 @@ def test_dispatch_order_changes_nothing_but_the_launch_time():
             assert np.array_equal(r[k], base[k]), k
     print(f"kernel ms: index order {t_base:.1f}, longest first {t_lpt:.1f}, shortest first {t_spt:.1f}")
     assert t_lpt < 0.95 * t_base and t_spt > t_lpt      # (at this batch size the longest instance alone is ~85 % of the launch)
+
+
+def test_latency_kernel_results_do_not_depend_on_the_wavefront_count():
+    """W = 2, 3, 4 wavefronts per instance evaluate the candidates of a line-search round with the same arithmetic as one
+    after the other: full solves are bit-identical (what lets the evaluator pick W by the number of running scenarios)."""
+    lay = nm.scenarios.ParamLayout()
+    P = nm.scenarios.make_batch(384, lay, seed=3, ped_mode="passing").astype(np.float32)
+    res = {}
+    for W in (2, 3, 4):
+        cfg = nm.default_config_struct()
+        cfg.latency_waves, cfg.max_active_dynobs = W, 10
+        with nm.Handle(cfg) as h:
+            res[W] = h.solve(P)
+        assert (res[W]["info"][:, 7] == W).all()
+    for W in (3, 4):
+        for k in ("U", "cost", "status", "iters"):
+            assert np.array_equal(res[2][k], res[W][k]), (W, k)
+    for dtype in (np.float64,):
+        r = {}
+        for W in (2, 4):
+            cfg = nm.default_config_struct()
+            cfg.latency_waves = W
+            with nm.Handle(cfg) as h:
+                r[W] = h.solve(P[:96].astype(dtype), dtype=dtype)
+        assert np.array_equal(r[2]["U"], r[4]["U"]) and np.array_equal(r[2]["iters"], r[4]["iters"])
