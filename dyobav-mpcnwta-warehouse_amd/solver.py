@@ -200,17 +200,26 @@ class BatchResult:
 
 
 class BatchSolver:
-    """B independent MPC problems per launch (robots x Monte-Carlo scenarios)."""
+    """B independent MPC problems per launch (robots x Monte-Carlo scenarios).
 
-    def __init__(self, config: Optional[NmpcConfigStruct] = None, dtype=np.float32):
+    ``dispatch_by_history`` (default on, batches of >= ``dispatch_min_batch`` problems): the evaluation counts of a call
+    rank the problems of the next call of the same size, longest first (``nmpc_set_dispatch_order``) -- in a
+    receding-horizon loop problem i of this time step resembles problem i of the previous one, and a launch that starts
+    its long solves first drains sooner. Pure scheduling: the results do not depend on it."""
+
+    def __init__(self, config: Optional[NmpcConfigStruct] = None, dtype=np.float32, dispatch_by_history: bool = True,
+                 dispatch_min_batch: int = 32768):
         self.config = config if config is not None else default_config_struct()
         self.dtype = np.dtype(dtype)
         self.handle = Handle(self.config)
         self.num_parameters = self.handle.np_
         self.num_decision_variables = self.handle.n
+        self.dispatch_by_history, self.dispatch_min_batch = dispatch_by_history, dispatch_min_batch
 
     def run_batch(self, P: np.ndarray, u0=None, y0=None, c0=None) -> BatchResult:
         out = self.handle.solve(np.asarray(P), u0=u0, y0=y0, c0=c0, dtype=self.dtype)
+        if self.dispatch_by_history and out["U"].shape[0] >= self.dispatch_min_batch:
+            self.handle.set_dispatch_order(np.argsort(-out["info"][:, 4], kind="stable").astype(np.int32))
         return BatchResult(out["U"], out["cost"], out["status"], out["iters"], out["y"], out["info"],
                            self.handle.last_kernel_ms(), [EXIT_STATUS_NAMES[int(s)] for s in out["status"]])
 
