@@ -199,7 +199,10 @@ class Handle:
     def set_dispatch_order(self, order=None):
         """Workgroup b of the following solves of ``len(order)`` instances takes instance ``order[b]`` (a permutation:
         numpy int32 array, or an int32 device tensor on the handle's stream; e.g. ``np.argsort(-previous_evals)`` =
-        longest first). The library copies it. ``None`` clears it."""
+        longest first). The library copies it: a host array before the call returns, a device tensor asynchronously on
+        the handle's stream -- so a tensor produced on another stream must be kept alive (and that stream synchronised)
+        by the caller; with ``set_stream(torch's current stream)`` the copy is ordered like any other torch operation.
+        ``None`` clears it."""
         if order is None:
             _check(self._lib.nmpc_set_dispatch_order(self._h, None, 0))
         elif isinstance(order, np.ndarray) or not hasattr(order, "data_ptr"):
