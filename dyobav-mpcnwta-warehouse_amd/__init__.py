@@ -23,9 +23,9 @@ Import of this package never touches the GPU; the library is loaded on first use
 """
 from . import scenarios  # noqa: F401
 from ._capi import (EXIT_STATUS_NAMES, EXPORTED_SYMBOLS, Handle, NmpcConfigStruct, NmpcError,  # noqa: F401
-                    default_config_struct, library_path, load_library)
+                    default_config_struct, layout_info, library_path, load_library)
 from .build import build as build_library  # noqa: F401
 from .solver import BatchSolver, OptimizerSolution, Solver, make_config, solver  # noqa: F401
 
-__all__ = ["BatchSolver", "OptimizerSolution", "Solver", "make_config", "solver", "scenarios", "Handle", "NmpcConfigStruct", "NmpcError", "default_config_struct", "load_library",
+__all__ = ["BatchSolver", "OptimizerSolution", "Solver", "make_config", "solver", "scenarios", "Handle", "NmpcConfigStruct", "NmpcError", "default_config_struct", "layout_info", "load_library",
            "library_path", "build_library", "EXIT_STATUS_NAMES", "EXPORTED_SYMBOLS"]

@@ -14,8 +14,8 @@ import numpy as np
 from . import build as _build
 
 EXIT_STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotFiniteComputation",
-                     "CapacityExceeded")
-ABI_VERSION = 2
+                     "CapacityExceeded", "NotAxisAligned")
+ABI_VERSION = 3
 
 
 class NmpcError(RuntimeError):
@@ -43,8 +43,20 @@ class NmpcConfigStruct(C.Structure):
         ("cbfgs_alpha", C.c_double), ("cbfgs_epsilon", C.c_double), ("sy_epsilon", C.c_double),
         ("latency_waves", C.c_int32), ("akkt_form", C.c_int32),
         ("max_solver_time_us", C.c_double),
-        ("coop_waves", C.c_int32), ("reserved1", C.c_int32), ("reg_table", C.c_int32), ("reserved0", C.c_int32),
+        ("coop_waves", C.c_int32), ("axis_aligned", C.c_int32), ("reg_table", C.c_int32), ("staged", C.c_int32),
+        ("polish", C.c_int32), ("polish_max_outer_iterations", C.c_int32), ("polish_max_inner_iterations", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("polish_tolerance", C.c_double), ("polish_delta_tolerance", C.c_double),
     ]
+
+
+class NmpcLayoutInfo(C.Structure):
+    """Mirror of ``struct nmpc_layout_info``."""
+    _fields_ = [("np", C.c_int32), ("lds_bytes_f32", C.c_int32), ("lds_bytes_f64", C.c_int32),
+                ("reg_slots_f32", C.c_int32), ("global_table_f32", C.c_int32), ("global_table_f64", C.c_int32),
+                ("ws_elems_f32", C.c_int64), ("ws_elems_f64", C.c_int64),
+                ("table_entries_f32", C.c_int32), ("table_entries_f64", C.c_int32),
+                ("dyn_cap", C.c_int32), ("reserved", C.c_int32)]
 
 
 class NmpcAssembleArgs(C.Structure):
@@ -57,12 +69,12 @@ class NmpcAssembleArgs(C.Structure):
 
 # every symbol include/nmpc_hip.h declares (checked by the CPU test-suite against the built library)
 EXPORTED_SYMBOLS = (
-    "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_param_len", "nmpc_set_stream", "nmpc_use_own_stream", "nmpc_set_pointer_mode",
+    "nmpc_default_config", "nmpc_layout", "nmpc_create", "nmpc_destroy", "nmpc_param_len", "nmpc_set_stream", "nmpc_use_own_stream", "nmpc_set_pointer_mode",
     "nmpc_set_dispatch_order",
     "nmpc_solve_batch_f32", "nmpc_solve_batch_f64", "nmpc_eval_batch_f32", "nmpc_eval_batch_f64",
     "nmpc_assemble_params_f32", "nmpc_assemble_params_f64",
     "nmpc_hypotheses_to_ellipses_f32", "nmpc_hypotheses_to_ellipses_f64",
-    "nmpc_last_kernel_ms", "nmpc_kernel_info", "nmpc_selftest", "nmpc_last_error",
+    "nmpc_last_kernel_ms", "nmpc_last_launch_info", "nmpc_kernel_info", "nmpc_selftest", "nmpc_last_error",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -94,12 +106,14 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     lib.nmpc_last_error.restype = C.c_char_p
     lib.nmpc_last_error.argtypes = []
     lib.nmpc_default_config.argtypes = [C.POINTER(NmpcConfigStruct)]
+    lib.nmpc_layout.argtypes = [C.POINTER(NmpcConfigStruct), C.POINTER(NmpcLayoutInfo)]
     lib.nmpc_create.argtypes = [C.POINTER(NmpcConfigStruct), C.POINTER(vp)]
     lib.nmpc_destroy.argtypes = [vp]
     lib.nmpc_param_len.argtypes = [vp]
     lib.nmpc_set_stream.argtypes = [vp, vp]
     lib.nmpc_use_own_stream.argtypes = [vp]
     lib.nmpc_set_pointer_mode.argtypes = [vp, i32]
+    lib.nmpc_set_dispatch_order.argtypes = [vp, vp, i32]
     for sfx in ("f32", "f64"):
         getattr(lib, "nmpc_solve_batch_" + sfx).argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32]
         getattr(lib, "nmpc_eval_batch_" + sfx).argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp]
@@ -108,6 +122,7 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
                                                                        C.c_double, C.c_double, i32, vp, vp]
     lib.nmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.nmpc_kernel_info.argtypes = [vp] + [C.POINTER(i32)] * 5
+    lib.nmpc_last_launch_info.argtypes = [vp, C.POINTER(i32 * 8)]
     lib.nmpc_selftest.argtypes = [vp]
     for name in EXPORTED_SYMBOLS:
         if name != "nmpc_last_error":
@@ -126,6 +141,13 @@ def default_config_struct() -> NmpcConfigStruct:
     cfg = NmpcConfigStruct()
     _check(load_library().nmpc_default_config(C.byref(cfg)))
     return cfg
+
+
+def layout_info(cfg: NmpcConfigStruct) -> NmpcLayoutInfo:
+    """``nmpc_layout``: the dimension bookkeeping of a configuration (no device needed)."""
+    out = NmpcLayoutInfo()
+    _check(load_library().nmpc_layout(C.byref(cfg), C.byref(out)))
+    return out
 
 
 def _suffix(dtype) -> str:
@@ -219,6 +241,13 @@ class Handle:
         ms = C.c_float()
         _check(self._lib.nmpc_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+    def last_launch_info(self) -> dict:
+        """Which kernel family / variant the last solve or eval call launched (``nmpc_last_launch_info``)."""
+        v = (C.c_int32 * 8)()
+        _check(self._lib.nmpc_last_launch_info(self._h, C.byref(v)))
+        return {"family": ("throughput", "latency", "cooperative")[v[0]], "axis_aligned": int(v[1]),
+                "staged_outer_iterations": int(v[2]), "polish_selected": int(v[3])}
 
     def kernel_info(self) -> dict:
         v = [C.c_int32() for _ in range(5)]

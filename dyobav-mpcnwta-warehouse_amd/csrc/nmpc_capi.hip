@@ -138,7 +138,7 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false)
             left_ne = std::max(0, cap - coop_reg_rows(N)) * (N + 1);
         }
     }
-    const int ne = L.rs ? cap + 1 : cap * (N + 1); // table entries provisioned in LDS / the workspace (register table: t = 0 rows + the dummy)
+    int ne = L.rs ? cap + 1 : cap * (N + 1); // table entries provisioned in LDS / the workspace (register table: t = 0 rows + the dummy)
     L.dyn_cap = cap;
     L.glb = false;
     L.ws_stride = 0;
@@ -170,6 +170,8 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false)
     }
     if (L.glb || (size_t)L.lds_total * elem_size <= kLdsLimit) break;
     L.glb = true; // second attempt: everything but the ellipse table in LDS
+    L.rs = 0;     // (the GLB kernels index the full [row][t] table: the register-table layout does not apply)
+    ne = cap * (N + 1);
     L.ws_stride = (long long)(nmpc::kEllStride + 1) * ne;
     }
     return L;
@@ -186,6 +188,9 @@ struct nmpc_handle_s {
     bool spec_ok[2] = {true, true}; // [f32, f64]
     bool coop_ok[2] = {true, true};
     int last_mode = 0;              // kernel of the last solve: 0 throughput, 1 latency (speculative), 2 cooperative
+    int last_axis = -1;             // axis-aligned variant: -1 not applicable, 0 general only, 1 AXIS only, 2 decided on the device
+    int last_staged = 0;            // pilot outer iterations of the last solve (0 = one launch)
+    int last_polish_selected = 0, last_polish_converged = -1;
     template <typename T>
     const Layout& lay() const
     {
@@ -199,6 +204,11 @@ struct nmpc_handle_s {
     DevBuf dP, dU, dcost, dstatus, diters, du0, dy, dc0, dinfo, dY2, dC2, dpsi, dgrad, df2, dws;
     DevBuf dorder;   // dispatch order of the next solves (nmpc_set_dispatch_order), order_B entries; 0 = none
     int order_B = 0;
+    DevBuf dflag;    // device flags of the twin launches ([0]: some ellipse of the batch is not axis-aligned)
+    DevBuf dresume, dorder2, dhist; // resumable solve: parked states, ranked order of the second launch, bucket counters
+    // polish: compact fp64 copies of the selected instances and their results
+    DevBuf psel, pP, pU0, pY, pC, pU, pcost, pstatus, piters, pinfo;
+    std::vector<int32_t> host_status, host_sel;
 };
 
 namespace {
@@ -216,11 +226,13 @@ constexpr int wpe(int f32_default)
 {
     return sizeof(T) == 8 ? NMPC_WPE_F64 : RS >= kRegSlotsLarge ? 2 : RS > 0 ? 3 : f32_default;
 }
-template <typename T, int LPS, bool GLB, int RS = 0>
+template <typename T, int LPS, bool GLB, int RS = 0, bool AXIS = false>
 __global__ __launch_bounds__(64, (wpe<T, RS>(NMPC_WPE_F32))) void solve_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    nmpc::solve_instance<T, LPS, GLB, RS>(kp, nmpc::dispatch_index(kp), reinterpret_cast<T*>(smem));
+    const int inst = nmpc::dispatch_index(kp);
+    if (inst < 0) return;
+    nmpc::solve_instance<T, LPS, GLB, RS, false, false, AXIS>(kp, inst, reinterpret_cast<T*>(smem));
 }
 
 // cooperative mode: up to kSpecWaves wavefronts per instance share every evaluation (nmpc_device.h, COOP)
@@ -228,7 +240,9 @@ template <typename T, int LPS, bool GLB>
 __global__ __launch_bounds__(64 * kSpecWaves, (sizeof(T) == 4 ? NMPC_SPEC_WPE_F32 : NMPC_WPE_F64)) void solve_coop_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    nmpc::solve_instance<T, LPS, GLB, 0, true>(kp, nmpc::dispatch_index(kp), reinterpret_cast<T*>(smem));
+    const int inst = nmpc::dispatch_index(kp);
+    if (inst < 0) return;
+    nmpc::solve_instance<T, LPS, GLB, 0, true>(kp, inst, reinterpret_cast<T*>(smem));
 }
 // ... with the obstacle table on chip instead of in global memory, for one lane per horizon step (N > 32), where it does
 // not fit LDS: EIGHT wavefronts (two per SIMD) keep 12 rows each in registers, the remaining rows live in LDS
@@ -236,25 +250,30 @@ template <bool HLP>
 __global__ __launch_bounds__(64 * kCoopRegWaves, 2) void solve_coop_reg_kernel(nmpc::KParams<float> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    nmpc::solve_instance<float, 1, false, kRegSlotsCoop, true, HLP>(kp, nmpc::dispatch_index(kp), reinterpret_cast<float*>(smem));
+    const int inst = nmpc::dispatch_index(kp);
+    if (inst < 0) return;
+    nmpc::solve_instance<float, 1, false, kRegSlotsCoop, true, HLP>(kp, inst, reinterpret_cast<float*>(smem));
 }
 
 // latency mode: kSpecWaves wavefronts per instance, speculative line search (nmpc_spec.h)
-template <typename T, int LPS, bool GLB, int RS = 0>
+template <typename T, int LPS, bool GLB, int RS = 0, bool AXIS = false>
 __global__ __launch_bounds__(64 * kSpecWaves, (wpe<T, RS>(NMPC_SPEC_WPE_F32))) void solve_spec_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    nmpc::solve_instance_spec<T, LPS, GLB, RS>(kp, nmpc::dispatch_index(kp), reinterpret_cast<T*>(smem));
+    const int inst = nmpc::dispatch_index(kp);
+    if (inst < 0) return;
+    nmpc::solve_instance_spec<T, LPS, GLB, RS, AXIS>(kp, inst, reinterpret_cast<T*>(smem));
 }
 
-template <typename T, int LPS, bool GLB, int RS = 0>
+template <typename T, int LPS, bool GLB, int RS = 0, bool AXIS = false>
 __global__ __launch_bounds__(64) void eval_kernel(nmpc::KParams<T> kp, nmpc::EvalParams<T> ep)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (nmpc::dispatch_index(kp) < 0) return; // (twin launch of the other variant)
     const int inst = blockIdx.x, N = kp.N;
-    nmpc::Instance<T, LPS, GLB, RS> I(kp, kp.P + (size_t)inst * kp.np, reinterpret_cast<T*>(smem),
-                                  GLB ? kp.ws + (long long)inst * kp.ws_stride : nullptr);
-    if (!I.load()) {
+    nmpc::Instance<T, LPS, GLB, RS, false, false, AXIS> I(kp, kp.P + (size_t)inst * kp.np, reinterpret_cast<T*>(smem),
+                                                        GLB ? kp.ws + (long long)inst * kp.ws_stride : nullptr);
+    if (I.load()) {
         if (I.lane == 0) ep.psi[inst] = __builtin_nanf("");
         return;
     }
@@ -276,6 +295,109 @@ __global__ __launch_bounds__(64) void eval_kernel(nmpc::KParams<T> kp, nmpc::Eva
     if (I.lane == 0) {
         ep.psi[inst] = psi;
         if (ep.f2sq) ep.f2sq[inst] = f2;
+    }
+}
+
+// ---- small data kernels around the solves ------------------------------------------------------------------------
+// Is some ellipse of the batch not axis-aligned (angle != 0)? One workgroup per instance over o_d[j][t][4]; *flag is
+// zeroed before the launch, any workgroup that finds a non-zero angle stores 1 (plain store: all writers agree).
+template <typename T>
+__global__ __launch_bounds__(256) void axis_scan_kernel(const T* P, int np, int off_od, int n_entries, int* flag)
+{
+    const T* s = P + (size_t)blockIdx.x * np + off_od;
+    bool skew = false;
+    for (int e = threadIdx.x; e < n_entries; e += 256) skew = skew || s[6 * e + 4] != T(0);
+    if (skew) *flag = 1;
+}
+
+// Resumable solve, ranking of the second launch: bucket = the top 10 bits of ||F2|| (as float; monotonic for values
+// >= 0) the pilot left in the parked state; finished instances go to bucket 0. Counting sort, descending.
+constexpr int kRankBuckets = 1024;
+template <typename T>
+__device__ __forceinline__ int rank_bucket(const T* resume, const int* status, int b)
+{
+    if (status[b] != -1) return 0;
+    const float f = (float)resume[(size_t)b * nmpc::kResumeStride + 6 * 64 + 3];
+    const unsigned bits = __float_as_uint(f >= 0.0f ? f : 0.0f) >> 21;
+    return (int)(bits < (unsigned)kRankBuckets ? bits : kRankBuckets - 1);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void rank_hist_kernel(const T* resume, const int* status, int B, int* hist)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B) atomicAdd(&hist[rank_bucket(resume, status, b)], 1);
+}
+// offs[q] = number of instances in buckets above q (one workgroup of kRankBuckets threads; reversed inclusive scan)
+__global__ __launch_bounds__(kRankBuckets) void rank_scan_kernel(const int* hist, int* offs)
+{
+    __shared__ int sh[kRankBuckets];
+    const int t = threadIdx.x;                 // t = 0 is the top bucket
+    const int mine = hist[kRankBuckets - 1 - t];
+    sh[t] = mine;
+    __syncthreads();
+    for (int d = 1; d < kRankBuckets; d <<= 1) {
+        const int add = t >= d ? sh[t - d] : 0;
+        __syncthreads();
+        sh[t] += add;
+        __syncthreads();
+    }
+    offs[kRankBuckets - 1 - t] = sh[t] - mine;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void rank_scatter_kernel(const T* resume, const int* status, int B, int* offs, int* order)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B) order[atomicAdd(&offs[rank_bucket(resume, status, b)], 1)] = b;
+}
+
+// Polish: fp64 copies of the selected instances' parameters and of the main solve's (u, y, c) / results back into the
+// caller's arrays where the continuation converged (nmpc_config.polish)
+template <typename T>
+__global__ __launch_bounds__(256) void polish_gather_kernel(const T* P, const T* U, const T* y, const T* info, const int* sel,
+                                                            int np, int n2, double* P64, double* U64, double* Y64, double* C64)
+{
+    const int i = blockIdx.x, b = sel[i];
+    const T* src = P + (size_t)b * np;
+    double* dst = P64 + (size_t)i * np;
+    for (int j = threadIdx.x; j < np; j += 256) dst[j] = (double)src[j];
+    if ((int)threadIdx.x < n2) {
+        U64[(size_t)i * n2 + threadIdx.x] = (double)U[(size_t)b * n2 + threadIdx.x];
+        Y64[(size_t)i * n2 + threadIdx.x] = (double)y[(size_t)b * n2 + threadIdx.x];
+    }
+    if (threadIdx.x == 0) C64[i] = (double)info[(size_t)b * 8 + 3];
+}
+// (info[:, 6] is the polish outcome when the polish is on: 0 for the instances it does not touch)
+template <typename T>
+__global__ __launch_bounds__(256) void polish_clear_flag_kernel(T* info, int B)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B) info[(size_t)b * 8 + 6] = T(0);
+}
+template <typename T>
+__global__ __launch_bounds__(128) void polish_scatter_kernel(const int* sel, const double* U64, const double* Y64, const double* cost64,
+                                                            const int* status64, const int* iters64, const double* info64, int n2,
+                                                            T* U, T* y, bool y_user, T* cost, int* iters, T* info, bool info_user)
+{
+    const int i = blockIdx.x, b = sel[i], t = threadIdx.x;
+    const bool ok = status64[i] == 0;
+    if (ok && t < n2) {
+        U[(size_t)b * n2 + t] = (T)U64[(size_t)i * n2 + t];
+        if (y_user) y[(size_t)b * n2 + t] = (T)Y64[(size_t)i * n2 + t];
+    }
+    if (t == 0) {
+        if (ok && cost) cost[b] = (T)cost64[i];
+        if (iters) {
+            iters[2 * b] += iters64[2 * i];
+            iters[2 * b + 1] += iters64[2 * i + 1];
+        }
+        if (info_user) {
+            T* o = info + (size_t)b * 8;
+            const double* q = info64 + (size_t)i * 8;
+            if (ok) o[0] = (T)q[0], o[1] = (T)q[1], o[2] = (T)q[2], o[3] = (T)q[3];
+            o[4] += (T)q[4];
+            o[5] += (T)q[5];
+            o[6] = ok ? T(1) : T(2);
+        }
     }
 }
 
@@ -309,6 +431,13 @@ __global__ __launch_bounds__(64) void selftest_kernel(int* fails)
             if (s1 != nmpc::ref_wave_sum(x) || s2 != nmpc::ref_wave_sum(T(2) - x) || s3 != nmpc::ref_wave_sum(T(5) * x)) bad |= 1024;
         }
         if (nmpc::read_lane(x, 17) != __shfl(x, 17, 64)) bad |= 64;
+        {
+            int a[4];
+            nmpc::class3_addresses(lane % 3, a);
+            T c1 = x, c2 = T(4) - x;
+            nmpc::class3_sum2(c1, c2, a);
+            if (c1 != nmpc::ref_class3_sum(x) || c2 != nmpc::ref_class3_sum(T(4) - x)) bad |= 2048;
+        }
     }
     if (bad) atomicOr(fails, bad);
 }
@@ -394,7 +523,7 @@ void eval_coop_kernel(nmpc::KParams<T> kp, nmpc::EvalParams<T> ep)
     I.cw_ = wave;
     I.CW_ = (int)(blockDim.x >> 6);
     I.coop_x = lds + kp.lds_xch;
-    if (!I.load()) {
+    if (I.load()) {
         if (threadIdx.x == 0) ep.psi[inst] = __builtin_nanf("");
         return;
     }
@@ -431,23 +560,31 @@ void (*pick_solve_coop_reg(int N))(nmpc::KParams<float>)
     return coop_helper_lanes(N) ? solve_coop_reg_kernel<true> : solve_coop_reg_kernel<false>;
 }
 
+// (the register-table variants exist for float with three lanes per step only; `axis`: their axis-aligned twins, null
+//  where there is none)
 template <typename T>
-SolveFn<T> pick_solve(int lps, bool glb, int rs = 0)
+SolveFn<T> pick_solve(int lps, bool glb, int rs = 0, bool axis = false)
 {
     if constexpr (sizeof(T) == 4) {
-        if (rs == kRegSlotsSmall && lps == 3 && !glb) return solve_kernel<T, 3, false, kRegSlotsSmall>;
-        if (rs == kRegSlotsLarge && lps == 3 && !glb) return solve_kernel<T, 3, false, kRegSlotsLarge>;
+        if (rs == kRegSlotsSmall && lps == 3 && !glb)
+            return axis ? solve_kernel<T, 3, false, kRegSlotsSmall, true> : solve_kernel<T, 3, false, kRegSlotsSmall>;
+        if (rs == kRegSlotsLarge && lps == 3 && !glb)
+            return axis ? solve_kernel<T, 3, false, kRegSlotsLarge, true> : solve_kernel<T, 3, false, kRegSlotsLarge>;
     }
+    if (axis) return nullptr;
     if (glb) return lps == 3 ? solve_kernel<T, 3, true> : lps == 2 ? solve_kernel<T, 2, true> : solve_kernel<T, 1, true>;
     return lps == 3 ? solve_kernel<T, 3, false> : lps == 2 ? solve_kernel<T, 2, false> : solve_kernel<T, 1, false>;
 }
 template <typename T>
-SolveFn<T> pick_solve_spec(int lps, bool glb, int rs = 0)
+SolveFn<T> pick_solve_spec(int lps, bool glb, int rs = 0, bool axis = false)
 {
     if constexpr (sizeof(T) == 4) {
-        if (rs == kRegSlotsSmall && lps == 3 && !glb) return solve_spec_kernel<T, 3, false, kRegSlotsSmall>;
-        if (rs == kRegSlotsLarge && lps == 3 && !glb) return solve_spec_kernel<T, 3, false, kRegSlotsLarge>;
+        if (rs == kRegSlotsSmall && lps == 3 && !glb)
+            return axis ? solve_spec_kernel<T, 3, false, kRegSlotsSmall, true> : solve_spec_kernel<T, 3, false, kRegSlotsSmall>;
+        if (rs == kRegSlotsLarge && lps == 3 && !glb)
+            return axis ? solve_spec_kernel<T, 3, false, kRegSlotsLarge, true> : solve_spec_kernel<T, 3, false, kRegSlotsLarge>;
     }
+    if (axis) return nullptr;
     if (glb) return lps == 3 ? solve_spec_kernel<T, 3, true> : lps == 2 ? solve_spec_kernel<T, 2, true> : solve_spec_kernel<T, 1, true>;
     return lps == 3 ? solve_spec_kernel<T, 3, false> : lps == 2 ? solve_spec_kernel<T, 2, false> : solve_spec_kernel<T, 1, false>;
 }
@@ -460,12 +597,15 @@ SolveFn<T> pick_solve_coop(int lps, bool glb)
 }
 
 template <typename T>
-EvalFn<T> pick_eval(int lps, bool glb, int rs = 0)
+EvalFn<T> pick_eval(int lps, bool glb, int rs = 0, bool axis = false)
 {
     if constexpr (sizeof(T) == 4) {
-        if (rs == kRegSlotsSmall && lps == 3 && !glb) return eval_kernel<T, 3, false, kRegSlotsSmall>;
-        if (rs == kRegSlotsLarge && lps == 3 && !glb) return eval_kernel<T, 3, false, kRegSlotsLarge>;
+        if (rs == kRegSlotsSmall && lps == 3 && !glb)
+            return axis ? eval_kernel<T, 3, false, kRegSlotsSmall, true> : eval_kernel<T, 3, false, kRegSlotsSmall>;
+        if (rs == kRegSlotsLarge && lps == 3 && !glb)
+            return axis ? eval_kernel<T, 3, false, kRegSlotsLarge, true> : eval_kernel<T, 3, false, kRegSlotsLarge>;
     }
+    if (axis) return nullptr;
     if (glb) return lps == 3 ? eval_kernel<T, 3, true> : lps == 2 ? eval_kernel<T, 2, true> : eval_kernel<T, 1, true>;
     return lps == 3 ? eval_kernel<T, 3, false> : lps == 2 ? eval_kernel<T, 2, false> : eval_kernel<T, 1, false>;
 }
@@ -518,45 +658,27 @@ int stage_out(nmpc_handle_s* h, DevBuf& buf, T* dst, size_t count, T** dev, bool
     return 0;
 }
 
+// ---- kernel choice and launch ---------------------------------------------------------------------------------------
 template <typename T>
-int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t* status, int32_t* iters,
-                const T* u0, T* y, int32_t y_is_input, const T* c0, T* info, int32_t sync)
-{
-    if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
-    if (!P || !U) return fail(NMPC_ERR_INVALID_ARGUMENT, "P and U must not be NULL");
-    if (B < 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "B = %d < 0", B);
-    if (B == 0) return 0;
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
-    const Layout& L = h->lay<T>();
-    const size_t n = 2 * (size_t)h->cfg.N_hor, np = L.np;
-    nmpc::KParams<T> k;
-    fill_kparams(h, k);
-    k.B = B;
-    k.y_is_input = y_is_input;
-    if (L.glb) {
-        if (int rc_ = h->dws.reserve((size_t)B * L.ws_stride * sizeof(T))) return rc_;
-        k.ws = static_cast<T*>(h->dws.p);
-        k.ws_stride = L.ws_stride;
-    }
-    bool hU, hcost, hstatus, hiters, hy, hinfo;
-    int rc;
-    if ((rc = stage_in(h, h->dP, P, (size_t)B * np, &k.P))) return rc;
-    if ((rc = stage_in(h, h->du0, u0, (size_t)B * n, &k.u0))) return rc;
-    if ((rc = stage_in(h, h->dc0, c0, (size_t)B, &k.c0v))) return rc;
-    if ((rc = stage_out(h, h->dU, U, (size_t)B * n, &k.U, &hU))) return rc;
-    if ((rc = stage_out(h, h->dcost, cost, (size_t)B, &k.cost, &hcost))) return rc;
-    if ((rc = stage_out(h, h->dstatus, status, (size_t)B, &k.status, &hstatus))) return rc;
-    if ((rc = stage_out(h, h->diters, iters, (size_t)B * 2, &k.iters, &hiters))) return rc;
-    if ((rc = stage_out(h, h->dy, y, (size_t)B * n, &k.y, &hy))) return rc;
-    const size_t info_row = 8 + nmpc::kProfSlots; // 8 in the shipped library (kProfSlots = 0)
-    if ((rc = stage_out(h, h->dinfo, info, (size_t)B * info_row, &k.info, &hinfo))) return rc;
-    if (hy && y_is_input) HIP_TRY(hipMemcpyAsync(k.y, y, (size_t)B * n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+struct Plan {
+    SolveFn<T> fn = nullptr, fn_axis = nullptr; // fn_axis: the axis-aligned twin (null = none)
+    int threads = 64;
+    size_t lds_bytes = 0;
+    int mode = 0;          // 0 throughput, 1 latency (speculative), 2 cooperative
+    bool uses_ws = false;  // the variant reads the global obstacle workspace
+    bool stageable = false;
+};
 
-    // latency mode (several wavefronts per instance) pays off while the batch leaves SIMDs idle
+// Which solve kernel runs a batch of B instances (measured crossovers). May re-fill `k` with the layout of the
+// on-chip cooperative kernel (the batch buffers are kept).
+template <typename T>
+Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
+{
+    const Layout& L = h->lay<T>();
+    Plan<T> pl;
     // wavefronts per instance: 0 = throughput kernel; > 0 = latency kernel (pays off while the batch leaves SIMDs idle)
     int lw = h->cfg.latency_waves;
-    // automatic: measured crossovers. fp64 runs 2 wavefronts per SIMD (256 VGPRs) against 3 in fp32, so
-    // fewer 4-wavefront workgroups are resident
+    // fp64 runs 2 wavefronts per SIMD (256 VGPRs) against 3 in fp32, so fewer 4-wavefront workgroups are resident
     const int cap = sizeof(T) == 4 ? h->n_simd : h->n_simd / 2;
     if (lw == 0) {
         // one workgroup per SIMD or less: as many wavefronts per instance as stay resident together (3 per SIMD in
@@ -595,11 +717,14 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
     int coop = h->cfg.coop_waves > kSpecWaves ? kSpecWaves : h->cfg.coop_waves;
     if (coop == 0) coop = (L.glb && h->cfg.latency_waves == 0) ? kSpecWaves : 1;
     if (L.rs > 0 || h->cfg.max_solver_time_us > 0 || !h->coop_ok[sizeof(T) == 4 ? 0 : 1]) coop = 1;
-    size_t lds_bytes = (size_t)(waves ? L.lds_total_spec : L.lds_total) * sizeof(T);
-    SolveFn<T> fn = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs) : pick_solve<T>(h->lps, L.glb, L.rs);
+    pl.lds_bytes = (size_t)(waves ? L.lds_total_spec : L.lds_total) * sizeof(T);
+    pl.fn = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs) : pick_solve<T>(h->lps, L.glb, L.rs);
+    pl.fn_axis = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs, true) : pick_solve<T>(h->lps, L.glb, L.rs, true);
+    pl.uses_ws = L.glb;
     if (coop > 1) {
-        fn = pick_solve_coop<T>(h->lps, L.glb);
-        lds_bytes = (size_t)L.lds_total_coop * sizeof(T);
+        pl.fn = pick_solve_coop<T>(h->lps, L.glb);
+        pl.fn_axis = nullptr;
+        pl.lds_bytes = (size_t)L.lds_total_coop * sizeof(T);
         k.lds_xch = L.lds_xch_coop;
         waves = coop;
         if constexpr (sizeof(T) == 4) {
@@ -612,19 +737,171 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
                 fill_kparams(h, k, &C);
                 k.B = keep.B, k.P = keep.P, k.U = keep.U, k.cost = keep.cost, k.status = keep.status, k.iters = keep.iters;
                 k.u0 = keep.u0, k.y = keep.y, k.y_is_input = keep.y_is_input, k.c0v = keep.c0v, k.info = keep.info;
-                k.ws = nullptr;
-                k.ws_stride = 0;
+                k.order = keep.order;
                 k.lds_xch = C.lds_xch_coop;
-                fn = pick_solve_coop_reg(h->cfg.N_hor);
-                lds_bytes = (size_t)C.lds_total_coop * sizeof(T);
+                pl.fn = pick_solve_coop_reg(h->cfg.N_hor);
+                pl.lds_bytes = (size_t)C.lds_total_coop * sizeof(T);
+                pl.uses_ws = false;
             }
         }
     }
-    k.order = h->order_B == B ? static_cast<const int*>(h->dorder.p) : nullptr;
-    h->last_mode = coop > 1 ? 2 : waves ? 1 : 0;
-    HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(fn, dim3(B), dim3(waves ? 64 * waves : 64), lds_bytes, h->stream, k);
+    pl.threads = waves ? 64 * waves : 64;
+    pl.mode = coop > 1 ? 2 : waves ? 1 : 0;
+    pl.stageable = pl.mode == 0 && h->cfg.max_solver_time_us <= 0;
+    return pl;
+}
+
+// one launch of the planned kernel over `grid` workgroups; with an axis-aligned twin: `axis` = 1 the twin only, 0 the
+// general kernel only, 2 both, gated by the flag the scan of the batch left on the device
+template <typename T>
+int launch_plan(nmpc_handle_s* h, const Plan<T>& pl, nmpc::KParams<T> k, int grid, int axis)
+{
+    if (axis != 0 && pl.fn_axis) {
+        if (axis == 2) {
+            k.gate = static_cast<const int*>(h->dflag.p);
+            k.gate_value = 0; // no skewed ellipse found
+        }
+        hipLaunchKernelGGL(pl.fn_axis, dim3(grid), dim3(pl.threads), pl.lds_bytes, h->stream, k);
+        HIP_TRY(hipGetLastError());
+        if (axis == 1) return 0;
+        k.gate_value = 1;
+    }
+    hipLaunchKernelGGL(pl.fn, dim3(grid), dim3(pl.threads), pl.lds_bytes, h->stream, k);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Decide how the axis-aligned twins take part in a call over B instances at P (device): 0 general only, 1 twin only
+// (caller's promise), 2 decided on the device (scan enqueued here).
+template <typename T>
+int prepare_axis(nmpc_handle_s* h, bool have_twin, const T* P, int B, int* mode)
+{
+    *mode = 0;
+    if (!have_twin || h->cfg.axis_aligned < 0) return 0;
+    if (h->cfg.axis_aligned > 0) {
+        *mode = 1;
+        return 0;
+    }
+    if (int rc = h->dflag.reserve(4 * sizeof(int))) return rc;
+    const Layout& L = h->lay<T>();
+    HIP_TRY(hipMemsetAsync(h->dflag.p, 0, sizeof(int), h->stream));
+    const int n_entries = h->cfg.Ndynobs * (h->cfg.N_hor + 1);
+    if (n_entries > 0) {
+        hipLaunchKernelGGL(axis_scan_kernel<T>, dim3(B), dim3(256), 0, h->stream, P, L.np, L.off_od, n_entries,
+                           static_cast<int*>(h->dflag.p));
+        HIP_TRY(hipGetLastError());
+    }
+    *mode = 2;
+    return 0;
+}
+
+// Solve B instances whose buffers (all on the device) are in `k`: kernel choice, the axis-aligned twin, the two-launch
+// resumable solve. `allow_staging`: the caller's status array may be used for the in-progress marker.
+template <typename T>
+int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
+{
+    const Layout& L = h->lay<T>();
+    Plan<T> pl = plan_solve<T>(h, B, k);
+    if (pl.uses_ws) {
+        if (int rc_ = h->dws.reserve((size_t)B * L.ws_stride * sizeof(T))) return rc_;
+        k.ws = static_cast<T*>(h->dws.p);
+        k.ws_stride = L.ws_stride;
+    } else {
+        k.ws = nullptr;
+        k.ws_stride = 0;
+    }
+    int axis = 0;
+    if (int rc = prepare_axis<T>(h, pl.fn_axis != nullptr, k.P, B, &axis)) return rc;
+    h->last_mode = pl.mode;
+    h->last_axis = pl.fn_axis ? axis : -1;
+    // resumable solve: automatic for batches that fill the device at least four times over with the one-wavefront kernel
+    int staged = h->cfg.staged;
+    if (staged == 0) {
+        const int wpe_tp = sizeof(T) == 8 ? NMPC_WPE_F64 : L.rs >= kRegSlotsLarge ? 2 : L.rs > 0 ? 3 : NMPC_WPE_F32;
+        const int resident = std::max(1, std::min<int>(wpe_tp * h->n_simd,
+                                                       (int)(kLdsLimit / ((size_t)L.lds_total * sizeof(T))) * (h->n_simd / 4)));
+        staged = B >= 4 * resident ? 1 : -1;
+    }
+    if (staged < 0 || !allow_staging || !pl.stageable || k.order || !k.status || staged >= h->cfg.max_outer_iterations) staged = 0;
+    h->last_staged = staged;
+    if (staged == 0) return launch_plan<T>(h, pl, k, B, axis);
+
+    if (int rc = h->dresume.reserve((size_t)B * nmpc::kResumeStride * sizeof(T))) return rc;
+    if (int rc = h->dorder2.reserve((size_t)B * sizeof(int))) return rc;
+    if (int rc = h->dhist.reserve(2 * kRankBuckets * sizeof(int))) return rc;
+    k.resume = static_cast<T*>(h->dresume.p);
+    nmpc::KParams<T> k1 = k;
+    k1.stage_outer_cap = staged;
+    if (int rc = launch_plan<T>(h, pl, k1, B, axis)) return rc;
+    int* hist = static_cast<int*>(h->dhist.p);
+    int* offs = hist + kRankBuckets;
+    int* order2 = static_cast<int*>(h->dorder2.p);
+    HIP_TRY(hipMemsetAsync(hist, 0, kRankBuckets * sizeof(int), h->stream));
+    const int nb = (B + 255) / 256;
+    hipLaunchKernelGGL(rank_hist_kernel<T>, dim3(nb), dim3(256), 0, h->stream, k.resume, k.status, B, hist);
+    hipLaunchKernelGGL(rank_scan_kernel, dim3(1), dim3(kRankBuckets), 0, h->stream, hist, offs);
+    hipLaunchKernelGGL(rank_scatter_kernel<T>, dim3(nb), dim3(256), 0, h->stream, k.resume, k.status, B, offs, order2);
+    HIP_TRY(hipGetLastError());
+    nmpc::KParams<T> k2 = k;
+    k2.stage_in = 1;
+    k2.order = order2;
+    return launch_plan<T>(h, pl, k2, B, axis);
+}
+
+template <typename T>
+int polish_batch(nmpc_handle_s* h, const nmpc::KParams<T>& k, int B, bool y_user, bool info_user);
+
+template <typename T>
+int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t* status, int32_t* iters,
+                const T* u0, T* y, int32_t y_is_input, const T* c0, T* info, int32_t sync)
+{
+    if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (!P || !U) return fail(NMPC_ERR_INVALID_ARGUMENT, "P and U must not be NULL");
+    if (B < 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "B = %d < 0", B);
+    if (B == 0) return 0;
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const Layout& L = h->lay<T>();
+    const size_t n = 2 * (size_t)h->cfg.N_hor, np = L.np;
+    nmpc::KParams<T> k;
+    fill_kparams(h, k);
+    k.B = B;
+    k.y_is_input = y_is_input;
+    bool hU, hcost, hstatus, hiters, hy, hinfo;
+    int rc;
+    if ((rc = stage_in(h, h->dP, P, (size_t)B * np, &k.P))) return rc;
+    if ((rc = stage_in(h, h->du0, u0, (size_t)B * n, &k.u0))) return rc;
+    if ((rc = stage_in(h, h->dc0, c0, (size_t)B, &k.c0v))) return rc;
+    if ((rc = stage_out(h, h->dU, U, (size_t)B * n, &k.U, &hU))) return rc;
+    if ((rc = stage_out(h, h->dcost, cost, (size_t)B, &k.cost, &hcost))) return rc;
+    if ((rc = stage_out(h, h->dstatus, status, (size_t)B, &k.status, &hstatus))) return rc;
+    if ((rc = stage_out(h, h->diters, iters, (size_t)B * 2, &k.iters, &hiters))) return rc;
+    if ((rc = stage_out(h, h->dy, y, (size_t)B * n, &k.y, &hy))) return rc;
+    const size_t info_row = 8 + nmpc::kProfSlots; // 8 in the shipped library (kProfSlots = 0)
+    if ((rc = stage_out(h, h->dinfo, info, (size_t)B * info_row, &k.info, &hinfo))) return rc;
+    if (hy && y_is_input) HIP_TRY(hipMemcpyAsync(k.y, y, (size_t)B * n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    // arrays the caller did not ask for but the resumable solve (status) / the polish (status, y, info) need: the
+    // handle's own buffers stand in
+    const bool polish = h->cfg.polish > 0 && nmpc::kProfSlots == 0;
+    const bool y_user = y != nullptr, info_user = info != nullptr;
+    if (!k.status) {
+        if ((rc = h->dstatus.reserve((size_t)B * sizeof(int32_t)))) return rc;
+        k.status = static_cast<int*>(h->dstatus.p);
+    }
+    if (polish && !k.y) {
+        if ((rc = h->dy.reserve((size_t)B * n * sizeof(T)))) return rc;
+        k.y = static_cast<T*>(h->dy.p);
+    }
+    if (polish && !k.info) {
+        if ((rc = h->dinfo.reserve((size_t)B * info_row * sizeof(T)))) return rc;
+        k.info = static_cast<T*>(h->dinfo.p);
+    }
+    k.order = h->order_B == B ? static_cast<const int*>(h->dorder.p) : nullptr;
+
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    if ((rc = run_solve<T>(h, k, B, true))) return rc;
+    h->last_polish_selected = 0;
+    h->last_polish_converged = -1;
+    if (polish && (rc = polish_batch<T>(h, k, B, y_user, info_user))) return rc;
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
 
@@ -642,6 +919,75 @@ int solve_batch(nmpc_handle_s* h, const T* P, int32_t B, T* U, T* cost, int32_t*
     return 0;
 }
 
+// nmpc_config.polish: fp64 continuation of the instances the main solve flagged Converged (results of the main solve
+// in k.U / k.y / k.info / k.status on the device). One stream synchronisation: the selection is made on the host.
+template <typename T>
+int polish_batch(nmpc_handle_s* h, const nmpc::KParams<T>& k, int B, bool y_user, bool info_user)
+{
+    const int n2 = 2 * h->cfg.N_hor;
+    h->host_status.resize((size_t)B);
+    HIP_TRY(hipMemcpyAsync(h->host_status.data(), k.status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->host_sel.clear();
+    for (int b = 0; b < B; ++b)
+        if (h->host_status[(size_t)b] == NMPC_CONVERGED) h->host_sel.push_back(b);
+    const int ns = (int)h->host_sel.size();
+    h->last_polish_selected = ns;
+    h->last_polish_converged = 0;
+    if (info_user) {
+        hipLaunchKernelGGL(polish_clear_flag_kernel<T>, dim3((B + 255) / 256), dim3(256), 0, h->stream, k.info, B);
+        HIP_TRY(hipGetLastError());
+    }
+    if (ns == 0) return 0;
+    const Layout& L64 = h->lay64;
+    const size_t np = (size_t)L64.np;
+    int rc;
+    if ((rc = h->psel.reserve((size_t)ns * sizeof(int)))) return rc;
+    if ((rc = h->pP.reserve((size_t)ns * np * sizeof(double)))) return rc;
+    if ((rc = h->pU0.reserve((size_t)ns * n2 * sizeof(double)))) return rc;
+    if ((rc = h->pY.reserve((size_t)ns * n2 * sizeof(double)))) return rc;
+    if ((rc = h->pC.reserve((size_t)ns * sizeof(double)))) return rc;
+    if ((rc = h->pU.reserve((size_t)ns * n2 * sizeof(double)))) return rc;
+    if ((rc = h->pcost.reserve((size_t)ns * sizeof(double)))) return rc;
+    if ((rc = h->pstatus.reserve((size_t)ns * sizeof(int)))) return rc;
+    if ((rc = h->piters.reserve((size_t)ns * 2 * sizeof(int)))) return rc;
+    if ((rc = h->pinfo.reserve((size_t)ns * 8 * sizeof(double)))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->psel.p, h->host_sel.data(), (size_t)ns * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    const int* sel = static_cast<const int*>(h->psel.p);
+    hipLaunchKernelGGL(polish_gather_kernel<T>, dim3(ns), dim3(256), 0, h->stream, k.P, (const T*)k.U, (const T*)k.y,
+                       (const T*)k.info, sel, (int)np, n2, static_cast<double*>(h->pP.p), static_cast<double*>(h->pU0.p),
+                       static_cast<double*>(h->pY.p), static_cast<double*>(h->pC.p));
+    HIP_TRY(hipGetLastError());
+    nmpc::KParams<double> q;
+    fill_kparams(h, q);
+    const nmpc_config& c = h->cfg;
+    q.tol = q.init_tol = c.polish_tolerance;
+    q.delta_tol = c.polish_delta_tolerance;
+    q.max_outer = c.polish_max_outer_iterations;
+    q.max_inner = c.polish_max_inner_iterations;
+    q.time_budget = 0;
+    q.B = ns;
+    q.P = static_cast<const double*>(h->pP.p);
+    q.u0 = static_cast<const double*>(h->pU0.p);
+    q.y = static_cast<double*>(h->pY.p);
+    q.y_is_input = 1;
+    q.c0v = static_cast<const double*>(h->pC.p);
+    q.U = static_cast<double*>(h->pU.p);
+    q.cost = static_cast<double*>(h->pcost.p);
+    q.status = static_cast<int*>(h->pstatus.p);
+    q.iters = static_cast<int*>(h->piters.p);
+    q.info = static_cast<double*>(h->pinfo.p);
+    const int keep_mode = h->last_mode, keep_axis = h->last_axis, keep_staged = h->last_staged;
+    rc = run_solve<double>(h, q, ns, false);
+    h->last_mode = keep_mode, h->last_axis = keep_axis, h->last_staged = keep_staged;
+    if (rc) return rc;
+    hipLaunchKernelGGL(polish_scatter_kernel<T>, dim3(ns), dim3(128), 0, h->stream, sel, (const double*)q.U, (const double*)q.y,
+                       (const double*)q.cost, (const int*)q.status, (const int*)q.iters, (const double*)q.info, n2, k.U, k.y,
+                       y_user, k.cost, k.iters, k.info, info_user);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <typename T>
 int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C, int32_t B, T* psi, T* grad,
                T* f2sq)
@@ -655,11 +1001,6 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
     nmpc::KParams<T> k;
     fill_kparams(h, k);
     k.B = B;
-    if (L.glb) {
-        if (int rc_ = h->dws.reserve((size_t)B * L.ws_stride * sizeof(T))) return rc_;
-        k.ws = static_cast<T*>(h->dws.p);
-        k.ws_stride = L.ws_stride;
-    }
     nmpc::EvalParams<T> ep;
     bool hpsi, hgrad, hf2;
     int rc;
@@ -671,12 +1012,14 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
     if ((rc = stage_out(h, h->dgrad, grad, (size_t)B * n, &ep.grad, &hgrad))) return rc;
     if ((rc = stage_out(h, h->df2, f2sq, (size_t)B, &ep.f2sq, &hf2))) return rc;
     size_t lds_bytes = (size_t)L.lds_total * sizeof(T);
-    EvalFn<T> fn = pick_eval<T>(h->lps, L.glb, L.rs);
+    EvalFn<T> fn = pick_eval<T>(h->lps, L.glb, L.rs), fn_axis = pick_eval<T>(h->lps, L.glb, L.rs, true);
+    bool uses_ws = L.glb;
     int waves = 1;
     // coop_waves > 1: evaluate through the cooperative kernels' code path (same variant choice as solve_batch)
     if (h->cfg.coop_waves > 1 && L.rs == 0 && h->coop_ok[sizeof(T) == 4 ? 0 : 1]) {
         waves = std::min<int>(h->cfg.coop_waves, kSpecWaves);
         fn = pick_eval_coop<T>(h->lps, L.glb);
+        fn_axis = nullptr;
         lds_bytes = (size_t)L.lds_total_coop * sizeof(T);
         k.lds_xch = L.lds_xch_coop;
         if constexpr (sizeof(T) == 4) {
@@ -685,17 +1028,40 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
                 const nmpc::KParams<T> keep = k;
                 fill_kparams(h, k, &C);
                 k.B = keep.B, k.P = keep.P;
-                k.ws = nullptr;
-                k.ws_stride = 0;
                 k.lds_xch = C.lds_xch_coop;
                 waves = kCoopRegWaves;
                 fn = pick_eval_coop_reg(h->cfg.N_hor);
                 lds_bytes = (size_t)C.lds_total_coop * sizeof(T);
+                uses_ws = false;
             }
         }
     }
-    hipLaunchKernelGGL(fn, dim3(B), dim3(64 * waves), lds_bytes, h->stream, k, ep);
-    HIP_TRY(hipGetLastError());
+    if (uses_ws) { // (only the variants that stream the obstacle table reserve the global workspace)
+        if (int rc_ = h->dws.reserve((size_t)B * L.ws_stride * sizeof(T))) return rc_;
+        k.ws = static_cast<T*>(h->dws.p);
+        k.ws_stride = L.ws_stride;
+    }
+    int axis = 0;
+    if ((rc = prepare_axis<T>(h, fn_axis != nullptr, k.P, B, &axis))) return rc;
+    h->last_mode = waves > 1 ? 2 : 0;
+    h->last_axis = fn_axis ? axis : -1;
+    h->last_staged = 0;
+    h->last_polish_selected = 0;
+    if (axis != 0 && fn_axis) {
+        nmpc::KParams<T> ka = k;
+        if (axis == 2) {
+            ka.gate = static_cast<const int*>(h->dflag.p);
+            ka.gate_value = 0;
+            k.gate = ka.gate;
+            k.gate_value = 1;
+        }
+        hipLaunchKernelGGL(fn_axis, dim3(B), dim3(64 * waves), lds_bytes, h->stream, ka, ep);
+        HIP_TRY(hipGetLastError());
+    }
+    if (axis != 1 || !fn_axis) {
+        hipLaunchKernelGGL(fn, dim3(B), dim3(64 * waves), lds_bytes, h->stream, k, ep);
+        HIP_TRY(hipGetLastError());
+    }
     if (hpsi) HIP_TRY(hipMemcpyAsync(psi, ep.psi, (size_t)B * sizeof(T), hipMemcpyDeviceToHost, h->stream));
     if (hgrad) HIP_TRY(hipMemcpyAsync(grad, ep.grad, (size_t)B * n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
     if (hf2) HIP_TRY(hipMemcpyAsync(f2sq, ep.f2sq, (size_t)B * sizeof(T), hipMemcpyDeviceToHost, h->stream));
@@ -824,6 +1190,10 @@ int set_lds_limit(nmpc_handle_s* h)
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_eval<T>(h->lps, L.glb, L.rs)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (auto f = pick_solve<T>(h->lps, L.glb, L.rs, true))
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (auto f = pick_eval<T>(h->lps, L.glb, L.rs, true))
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
     if (sizeof(T) == 4 && h->lay32c.rs > 0) {
         const size_t cb = (size_t)h->lay32c.lds_total_coop * sizeof(float);
@@ -849,6 +1219,8 @@ int set_lds_limit(nmpc_handle_s* h)
     } else if (spec_bytes > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve_spec<T>(h->lps, L.glb, L.rs)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)spec_bytes));
+        if (auto f = pick_solve_spec<T>(h->lps, L.glb, L.rs, true))
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)spec_bytes));
     }
     return 0;
 }
@@ -902,8 +1274,40 @@ int nmpc_default_config(nmpc_config* c)
     c->akkt_form = 0;
     c->max_solver_time_us = 0.0;
     c->coop_waves = 0;
-    c->reserved1 = 0;
+    c->axis_aligned = 0;
     c->reg_table = 0;
+    c->staged = 0;
+    c->polish = 0;
+    c->polish_max_outer_iterations = 4;
+    c->polish_max_inner_iterations = 300;
+    c->reserved0 = 0;
+    c->polish_tolerance = 1e-6;
+    c->polish_delta_tolerance = 1e-5;
+    return 0;
+}
+
+int nmpc_layout(const nmpc_config* cfg, nmpc_layout_info* out)
+{
+    if (!cfg || !out) return fail(NMPC_ERR_INVALID_ARGUMENT, "null argument");
+    if (cfg->abi_version != NMPC_ABI_VERSION)
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "abi_version %d != %d", cfg->abi_version, NMPC_ABI_VERSION);
+    if (cfg->N_hor < 1 || cfg->N_hor > NMPC_MAX_HORIZON || cfg->Nother < 1 || cfg->Nstcobs < 0 || cfg->Ndynobs < 0 ||
+        cfg->max_active_dynobs < 0)
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "bad dimensions");
+    const Layout a = make_layout(*cfg, sizeof(float)), b = make_layout(*cfg, sizeof(double));
+    std::memset(out, 0, sizeof *out);
+    out->np = a.np;
+    out->lds_bytes_f32 = (int32_t)((size_t)a.lds_total * sizeof(float));
+    out->lds_bytes_f64 = (int32_t)((size_t)b.lds_total * sizeof(double));
+    out->reg_slots_f32 = a.rs;
+    out->global_table_f32 = a.glb ? 1 : 0;
+    out->global_table_f64 = b.glb ? 1 : 0;
+    out->ws_elems_f32 = a.ws_stride;
+    out->ws_elems_f64 = b.ws_stride;
+    const int N1 = cfg->N_hor + 1;
+    out->table_entries_f32 = a.rs ? a.dyn_cap + 1 : a.dyn_cap * N1;
+    out->table_entries_f64 = b.dyn_cap * N1;
+    out->dyn_cap = a.dyn_cap;
     return 0;
 }
 
@@ -932,7 +1336,14 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "akkt_form = %d (0 = OpEn source form, 1 = documented form)", cfg->akkt_form);
     if (!(cfg->max_solver_time_us >= 0))
         return fail(NMPC_ERR_INVALID_ARGUMENT, "max_solver_time_us < 0");
-    if (cfg->reserved0 != 0 || cfg->reserved1 != 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "reserved fields must be 0");
+    if (cfg->reserved0 != 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "reserved fields must be 0");
+    if (cfg->axis_aligned < -1 || cfg->axis_aligned > 1)
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "axis_aligned = %d (0 automatic, 1 promised, -1 never)", cfg->axis_aligned);
+    if (cfg->staged < -1) return fail(NMPC_ERR_INVALID_ARGUMENT, "staged = %d < -1", cfg->staged);
+    if (cfg->polish != 0 && cfg->polish != 1) return fail(NMPC_ERR_INVALID_ARGUMENT, "polish = %d (0 or 1)", cfg->polish);
+    if (cfg->polish && (!(cfg->polish_tolerance > 0) || !(cfg->polish_delta_tolerance > 0) ||
+                        cfg->polish_max_outer_iterations < 1 || cfg->polish_max_inner_iterations < 1))
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "bad polish tolerances / iteration caps");
     if (!(cfg->ts > 0) || cfg->max_outer_iterations < 1 || cfg->max_inner_iterations < 1 ||
         !(cfg->initial_penalty > 0))
         return fail(NMPC_ERR_INVALID_ARGUMENT, "bad ts / iteration caps / initial penalty");
@@ -988,7 +1399,9 @@ int nmpc_destroy(nmpc_handle h)
     (void)hipSetDevice(h->cfg.device_id);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (DevBuf* b : {&h->dP, &h->dU, &h->dcost, &h->dstatus, &h->diters, &h->du0, &h->dy, &h->dc0, &h->dinfo,
-                      &h->dY2, &h->dC2, &h->dpsi, &h->dgrad, &h->df2, &h->dws})
+                      &h->dY2, &h->dC2, &h->dpsi, &h->dgrad, &h->df2, &h->dws, &h->dorder, &h->dflag, &h->dresume,
+                      &h->dorder2, &h->dhist, &h->psel, &h->pP, &h->pU0, &h->pY, &h->pC, &h->pU, &h->pcost, &h->pstatus,
+                      &h->piters, &h->pinfo})
         b->release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1108,6 +1521,17 @@ int nmpc_last_kernel_ms(nmpc_handle h, float* ms)
     if (!h->timed) return fail(NMPC_ERR_INVALID_ARGUMENT, "no solve has been launched on this handle yet");
     HIP_TRY(hipEventSynchronize(h->ev1));
     HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return 0;
+}
+
+int nmpc_last_launch_info(nmpc_handle h, int32_t out[8])
+{
+    if (!h || !out) return fail(NMPC_ERR_INVALID_ARGUMENT, "null argument");
+    std::memset(out, 0, 8 * sizeof(int32_t));
+    out[0] = h->last_mode;
+    out[1] = h->last_axis;
+    out[2] = h->last_staged;
+    out[3] = h->last_polish_selected;
     return 0;
 }
 

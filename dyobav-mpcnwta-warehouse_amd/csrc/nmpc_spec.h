@@ -28,7 +28,7 @@ namespace nmpc {
 
 enum SpecPhase : int { SP_INIT_A, SP_INIT_B, SP_LIP, SP_SPEC0, SP_NOLS, SP_LSN, SP_OUTER };
 
-template <typename T, int LPS, bool GLB, int RS = 0>
+template <typename T, int LPS, bool GLB, int RS = 0, bool AXIS = false>
 __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const int inst, T* lds)
 {
     // W is a run-time value (workgroup size / 64, at most kMaxSpecWaves) so that every choice of W executes the very
@@ -39,8 +39,8 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     const int MAX_LIP = 10, MAX_LS = 10;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 
-    Instance<T, LPS, GLB, RS> I(kp, kp.P + (size_t)inst * kp.np, lds, GLB ? kp.ws + (long long)inst * kp.ws_stride : nullptr);
-    if (!I.load()) { // NMPC_CAPACITY_EXCEEDED (uniform over the workgroup)
+    Instance<T, LPS, GLB, RS, false, false, AXIS> I(kp, kp.P + (size_t)inst * kp.np, lds, GLB ? kp.ws + (long long)inst * kp.ws_stride : nullptr);
+    if (const int bad = I.load()) { // NMPC_CAPACITY_EXCEEDED / NMPC_NOT_AXIS_ALIGNED (uniform over the workgroup)
         const T nan = __builtin_nanf("");
         const auto* kc = cold_args<T>();
         if (wave == 0) {
@@ -50,7 +50,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             }
             if (I.lane == 0) {
                 if (kc->cost) kc->cost[inst] = nan;
-                if (kc->status) kc->status[inst] = 4;
+                if (kc->status) kc->status[inst] = bad;
                 if (kc->iters) kc->iters[2 * inst] = kc->iters[2 * inst + 1] = 0;
                 if (kc->info)
                     for (int i = 0; i < 8 + kProfSlots; ++i) kc->info[(size_t)inst * (8 + kProfSlots) + i] = 0;

@@ -238,6 +238,49 @@ __device__ __forceinline__ void wave_scan_suffix_incl2(double& x, double& y)
     x = wave_scan_suffix_incl(x);
     y = wave_scan_suffix_incl(y);
 }
+// Stride-3 all-reduce of two values at once: every lane gets the sums of x and of y over the lanes of its own residue
+// class lane % 3 (three lanes per horizon step: the class = the obstacle row a lane owns in a slot of the register
+// table, the sum runs over the horizon steps). In-row partial sums with three DPP steps (row_shr 3 / 6 / 12: the last
+// lane of each class in a 16-lane row ends up with the class's sum over that row), then each lane fetches the four row
+// partials of its class through the LDS crossbar (ds_bpermute, no memory touched) -- 10 instructions per value for all
+// three classes, against three masked full-wave reductions. `a[q]` = 4 * (last lane of this lane's class in row q),
+// see class3_addresses().
+__device__ __forceinline__ void class3_sum2(float& x, float& y, const int (&a)[4])
+{
+    asm("s_nop 0\n\t" NMPC_P2("row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+            NMPC_P2("row_shr:6 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                NMPC_P2("row_shr:12 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        : "+v"(x), "+v"(y));
+    const float x0 = bperm(x, a[0]), x1 = bperm(x, a[1]), x2 = bperm(x, a[2]), x3 = bperm(x, a[3]);
+    const float y0 = bperm(y, a[0]), y1 = bperm(y, a[1]), y2 = bperm(y, a[2]), y3 = bperm(y, a[3]);
+    x = (x0 + x1) + (x2 + x3);
+    y = (y0 + y1) + (y2 + y3);
+}
+__device__ __forceinline__ void class3_sum2(double& x, double& y, const int (&a)[4])
+{
+    auto rows = [](double v) {
+        v += dpp_mov<DPP_ROW_SHR0 + 3, 0xf, 0xf, true>(0.0, v);
+        v += dpp_mov<DPP_ROW_SHR0 + 6, 0xf, 0xf, true>(0.0, v);
+        v += dpp_mov<DPP_ROW_SHR0 + 12, 0xf, 0xf, true>(0.0, v);
+        return v;
+    };
+    x = rows(x);
+    y = rows(y);
+    x = (bperm(x, a[0]) + bperm(x, a[1])) + (bperm(x, a[2]) + bperm(x, a[3]));
+    y = (bperm(y, a[0]) + bperm(y, a[1])) + (bperm(y, a[2]) + bperm(y, a[3]));
+}
+// byte addresses (ds_bpermute) of the last lane of residue class r = lane % 3 in each of the four 16-lane rows:
+// rows start at lanes 0, 16, 32, 48 = classes 0, 1, 2, 0, so the last lanes are 15/13/14, 30/31/29, 45/46/47, 63/61/62.
+// Three byte lookups in packed constants (a shift and three bit-field extracts) + one OR: cheap enough to be redone
+// where the addresses are needed instead of occupying four registers for a whole evaluation.
+__device__ __forceinline__ void class3_addresses(int r, int (&a)[4])
+{
+    const unsigned sh = (unsigned)r << 3;
+    a[0] = (int)((0x38343Cu >> sh) & 0xffu); // 4 * {15, 13, 14}
+    a[1] = (int)((0x747C78u >> sh) & 0xffu); // 4 * {30, 31, 29}
+    a[2] = (int)((0xBCB8B4u >> sh) & 0xffu); // 4 * {45, 46, 47}
+    a[3] = a[0] | 0xC0;                      // 4 * {63, 61, 62} = a[0] + 4 * 48
+}
 #undef NMPC_P2
 #undef NMPC_P3
 
@@ -271,6 +314,17 @@ __device__ inline T ref_wave_sum(T x)
 {
     T s = 0;
     for (int i = 0; i < 64; ++i) s += __shfl(x, i, 64);
+    return s;
+}
+template <typename T>
+__device__ inline T ref_class3_sum(T x)
+{
+    const int lane = threadIdx.x & 63;
+    T s = 0;
+    for (int i = 0; i < 64; ++i) {
+        T v = __shfl(x, i, 64);
+        if (i % 3 == lane % 3) s += v;
+    }
     return s;
 }
 template <typename T>

@@ -104,8 +104,9 @@ class Solver:
 
     def run(self, p, initial_guess=None, initial_lagrange_multipliers=None, initial_penalty=None):
         n = self.num_decision_variables
-        if len(p) != self.num_parameters:
-            print(f"1600 -> wrong number of parameters: expected {self.num_parameters}, got {len(p)}")
+        p = np.asarray(p).ravel()        # list, 1-D array or (1, np)-shaped array, as OpEn's binding accepts them
+        if p.size != self.num_parameters:
+            print(f"1600 -> wrong number of parameters: expected {self.num_parameters}, got {p.size}")
             return None
         b = self._bufs
         b["P"][0, :] = p

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised differential check of the f1 kernel (device-side parameter assembly; run by hand on the GPU box, not
-collected by pytest): random dimensions (N, Nother, Nstcobs, Ndynobs), map sizes (0 .. 200 polygons: fewer than slots,
+"""Randomised differential check of the f1 kernel (device-side parameter assembly; by hand on the GPU box for long runs, a
+reduced run with fixed seeds is part of the -m gpu suite through tests/test_gpu_fuzz.py): random dimensions (N, Nother, Nstcobs, Ndynobs), map sizes (0 .. 200 polygons: fewer than slots,
 one per lane, selection rounds), numbers of obstacle rows, with and without the fleet block, fp64 and fp32, against
 oracle/assemble.py -- every element of P, including the nearest-first order of the chosen polygons.
     python tests/fuzz_assemble.py [cases] [seed]"""
@@ -17,9 +17,8 @@ from oracle import assemble as oa           # noqa: E402
 from dyobav_mpcnwta_warehouse_amd.scenarios import ParamLayout  # noqa: E402
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def run(cases=100, seed=0, out=print):
+    rng = np.random.default_rng(seed)
     checked, worst = 0, 0.0
     for ci in range(cases):
         N, Nother = int(rng.integers(2, 65)), int(rng.integers(1, 13))
@@ -62,12 +61,12 @@ def main():
                 worst = max(worst, float(np.nanmax(err)))
                 if np.isnan(P[b]).any() or not (err < max(tol, 1e-9 if dt == np.float64 else 2e-3)).all():
                     k = int(np.nanargmax(np.where(np.isnan(P[b]), np.inf, err)))
-                    print(f"MISMATCH case {ci}: N={N} Nother={Nother} Nstc={Nstc} Ndyn={Ndyn} M={M} n_dyn={n_dyn} B={B} "
+                    out(f"MISMATCH case {ci}: N={N} Nother={Nother} Nstc={Nstc} Ndyn={Ndyn} M={M} n_dyn={n_dyn} B={B} "
                           f"dtype={np.dtype(dt).name} instance {b} element {k} (o_s block {lay.os}..{lay.od}): {P[b][k]} vs {want[k]}")
                     return 1
-    print(f"{cases} cases, {checked} parameter vectors checked element by element; worst relative error {worst:.2e}")
+    out(f"{cases} cases, {checked} parameter vectors checked element by element; worst relative error {worst:.2e}")
     return 0
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(run(*[int(x) for x in sys.argv[1:3]]))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised differential check (run by hand on the GPU box; not collected by pytest):
+"""Randomised differential check (by hand on the GPU box for long runs; a reduced run with fixed seeds is part of the
+-m gpu suite through tests/test_gpu_fuzz.py):
 psi / grad psi / ||F2||^2 through nmpc_eval_batch_* against the fp64 oracle for random problem dimensions, random
 numbers of active obstacle rows placed on the robot's path (so that soft AND hard ellipse terms are active), non-zero
 fleet robots and boxes, in every evaluation code path: register / LDS / global obstacle table with one wavefront,
@@ -17,7 +18,11 @@ import oracle                               # noqa: E402
 from dyobav_mpcnwta_warehouse_amd.scenarios import ParamLayout  # noqa: E402
 
 
-def make_case(rng):
+def make_case(rng, axis_aligned=None):
+    """`axis_aligned`: every ellipse with angle 0 (what the reference's producer writes, and what selects the AXIS kernel
+    variants); None = one case in three."""
+    if axis_aligned is None:
+        axis_aligned = rng.random() < 0.34
     N = int(rng.choice([rng.integers(3, 65), 20, 21, 22, 32, 33, 40, 42, 43, 64]))
     Nother, Nstc = int(rng.integers(1, 13)), int(rng.integers(1, 15))
     Ndyn = int(rng.choice([rng.integers(1, 30), rng.integers(30, 220), 12, 13, 42, 43, 96, 97, 144, 145, 160]))
@@ -35,7 +40,7 @@ def make_case(rng):
             ctr = path[rng.integers(0, N)] + rng.normal(0, 0.3, 2)
             od[b, j, :, 0:2] = ctr + np.arange(N + 1)[:, None] * rng.normal(0, 0.03, 2)
             od[b, j, :, 2:4] = rng.uniform(0.2, 0.9, 2)
-            od[b, j, :, 4] = rng.uniform(-1.5, 1.5) if rng.random() < 0.7 else 0.0
+            od[b, j, :, 4] = rng.uniform(-1.5, 1.5) if (rng.random() < 0.7 and not axis_aligned) else 0.0
             od[b, j, :, 5] = rng.uniform(0.0, 1.0, N + 1)
     P[:, lay.od:lay.od + od[0].size] = od.reshape(B, -1)
     # fleet: some robots with non-zero positions near the path
@@ -49,9 +54,9 @@ def make_case(rng):
     return lay, rows, P, U, Y, C
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def run(cases=100, seed=0, out=print):
+    """returns 0 when every evaluation agrees with the oracle"""
+    rng = np.random.default_rng(seed)
     worst = {}
     kinks = []
     n_checks = 0
@@ -60,6 +65,7 @@ def main():
         pr = oracle.Problem(lay.N, lay.Nother, lay.Nstc, lay.Ndyn)
         B = P.shape[0]
         modes = [("one-wave", dict(coop_waves=1, reg_table=0)), ("one-wave/lds", dict(coop_waves=1, reg_table=-1)),
+                 ("one-wave/general", dict(coop_waves=1, reg_table=0, axis_aligned=-1)),
                  ("coop4", dict(coop_waves=4, reg_table=0)), ("coop4/lds", dict(coop_waves=4, reg_table=-1)),
                  ("coop%d" % (2 + ci % 2), dict(coop_waves=2 + ci % 2, reg_table=-1))]
         for dtype, tp, tg in ((np.float64, 1e-10, 1e-9), (np.float32, 2e-4, 2e-3)):
@@ -94,17 +100,17 @@ def main():
                         if jump / max(1.0, np.abs(g).max()) > 0.3 * eg:
                             kinks.append((ci, name, np.dtype(dtype).name, i))
                             continue
-                        print(f"MISMATCH case {ci} N={lay.N} Nother={lay.Nother} Nstc={lay.Nstc} Ndyn={lay.Ndyn} rows={rows} "
+                        out(f"MISMATCH case {ci} N={lay.N} Nother={lay.Nother} Nstc={lay.Nstc} Ndyn={lay.Ndyn} rows={rows} "
                               f"mode={name} dtype={np.dtype(dtype).name} instance {i}: psi {ep:.2e} grad {eg:.2e} f2 {ef:.2e}")
                         return 1
                     w = worst.setdefault(key, [0.0, 0.0, 0.0])
                     w[0], w[1], w[2] = max(w[0], ep), max(w[1], eg), max(w[2], ef)
-    print(f"{cases} cases, {n_checks} evaluations checked, {len(kinks)} of them on a gradient kink (skipped: {kinks[:4]}); "
-          f"worst relative errors (psi, grad, f2sq):")
+    out(f"{cases} cases, {n_checks} evaluations checked, {len(kinks)} of them on a gradient kink (skipped: {kinks[:4]}); "
+        f"worst relative errors (psi, grad, f2sq):")
     for k, w in sorted(worst.items()):
-        print(f"  {k[0]:14s} {k[1]:8s} {w[0]:.2e} {w[1]:.2e} {w[2]:.2e}")
+        out(f"  {k[0]:16s} {k[1]:8s} {w[0]:.2e} {w[1]:.2e} {w[2]:.2e}")
     return 0
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised differential check of short SOLVES (run by hand on the GPU box; not collected by pytest): fp64, one outer
+"""Randomised differential check of short SOLVES (by hand on the GPU box for long runs; a reduced run with fixed seeds is
+part of the -m gpu suite through tests/test_gpu_fuzz.py): fp64, one outer
 x four inner iterations, every solver kernel (throughput, latency with 2..4 wavefronts, cooperative with 2..4, automatic)
 against the sequential oracle on the cases of tests/fuzz_eval.py -- iteration counts, exit status and controls.
     python tests/fuzz_solve.py [cases] [seed] [outer] [inner]
@@ -18,11 +19,8 @@ import oracle                               # noqa: E402
 from fuzz_eval import make_case             # noqa: E402
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    n_outer = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-    n_inner = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+def run(cases=100, seed=0, n_outer=1, n_inner=4, out=print):
+    rng = np.random.default_rng(seed)
     short = n_outer * n_inner <= 4   # longer runs: rounding differences grow ~4x per iteration on these instances
     worst, flips, total, dus = {}, {}, 0, {}
     for ci in range(cases):
@@ -51,14 +49,15 @@ def main():
                 worst[key] = max(worst.get(key, 0.0), du)
                 dus.setdefault(key, []).append(du)
                 if not np.isfinite(r["U"][i]).all() or (short and not du < 1e-5):
-                    print(f"MISMATCH case {ci} N={lay.N} Nother={lay.Nother} Nstc={lay.Nstc} Ndyn={lay.Ndyn} rows={rows} mode={name} "
+                    out(f"MISMATCH case {ci} N={lay.N} Nother={lay.Nother} Nstc={lay.Nstc} Ndyn={lay.Ndyn} rows={rows} mode={name} "
                           f"instance {i}: max|du| = {du:.3e}")
                     return 1
-    print(f"{cases} cases, {total} solves checked against the oracle (fp64, {n_outer} x {n_inner} iterations)")
+    out(f"{cases} cases, {total} solves checked against the oracle (fp64, {n_outer} x {n_inner} iterations)")
     for k in sorted(worst):
-        print(f"  {k:12s} max|u - u_oracle|: median {np.median(dus[k]):.2e}, worst {worst[k]:.2e}   iteration-count differences {flips.get(k, 0)}")
+        out(f"  {k:12s} max|u - u_oracle|: median {np.median(dus[k]):.2e}, worst {worst[k]:.2e}   iteration-count differences {flips.get(k, 0)}")
     return 0
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    a = [int(x) for x in sys.argv[1:]]
+    sys.exit(run(*a))

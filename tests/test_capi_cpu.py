@@ -27,26 +27,32 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_config_struct_matches_header_defaults():
     cfg = nm.default_config_struct()
-    assert cfg.abi_version == 2
+    assert cfg.abi_version == 3
     assert (cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs) == (20, 10, 10, 15)
     assert cfg.ts == 0.2 and cfg.lin_vel_max == 1.5 and cfg.ang_acc_max == 3.0
     assert cfg.tolerance == 1e-4 and cfg.initial_penalty == 10.0 and cfg.max_inner_iterations == 500
     assert cfg.max_outer_iterations == 10 and cfg.lbfgs_memory == 10
     assert cfg.latency_waves == 0 and cfg.akkt_form == 0 and cfg.max_solver_time_us == 0.0
-    assert cfg.coop_waves == 0 and cfg.reserved1 == 0 and cfg.reg_table == 0 and cfg.reserved0 == 0
+    assert cfg.coop_waves == 0 and cfg.axis_aligned == 0 and cfg.reg_table == 0 and cfg.staged == 0
+    assert cfg.polish == 0 and cfg.polish_max_outer_iterations == 4 and cfg.polish_max_inner_iterations == 300
+    assert cfg.polish_tolerance == 1e-6 and cfg.polish_delta_tolerance == 1e-5 and cfg.reserved0 == 0
     # struct size and a late field's offset: ctypes mirror vs the C compiler on include/nmpc_hip.h (catches field drift)
     import subprocess, tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "sz.c")
-        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "nmpc_hip.h"\nint main(void){printf("%zu %zu %zu %zu", '
-                             'sizeof(nmpc_config), offsetof(nmpc_config, latency_waves), offsetof(nmpc_config, initial_penalty), offsetof(nmpc_config, reg_table));return 0;}\n')
+        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "nmpc_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu", '
+                             'sizeof(nmpc_config), offsetof(nmpc_config, latency_waves), offsetof(nmpc_config, initial_penalty), offsetof(nmpc_config, reg_table), '
+                             'offsetof(nmpc_config, polish_delta_tolerance), sizeof(nmpc_layout_info));return 0;}\n')
         exe = os.path.join(td, "sz")
         subprocess.run(["gcc", "-I", os.path.join(root, "include"), src, "-o", exe], check=True)
-        size, off_lw, off_ip, off_gram = map(int, subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split())
-    assert ctypes.sizeof(nm.NmpcConfigStruct) == size == 6 * 4 + 13 * 8 + 4 * 4 + 11 * 8 + 2 * 4 + 8 + 4 * 4
+        size, off_lw, off_ip, off_gram, off_pd, size_li = map(int, subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split())
+    assert ctypes.sizeof(nm.NmpcConfigStruct) == size == 6 * 4 + 13 * 8 + 4 * 4 + 11 * 8 + 2 * 4 + 8 + 4 * 4 + 4 * 4 + 2 * 8
     assert nm.NmpcConfigStruct.latency_waves.offset == off_lw and nm.NmpcConfigStruct.initial_penalty.offset == off_ip
     assert nm.NmpcConfigStruct.reg_table.offset == off_gram
+    assert nm.NmpcConfigStruct.polish_delta_tolerance.offset == off_pd
+    from dyobav_mpcnwta_warehouse_amd._capi import NmpcLayoutInfo
+    assert ctypes.sizeof(NmpcLayoutInfo) == size_li
 
 
 def test_no_cpu_fallback_without_device():
@@ -84,3 +90,29 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "nmpc_oracle" not in src, f
+
+
+def test_layout_bookkeeping_without_a_device():
+    """nmpc_layout: the dimension bookkeeping nmpc_create would do. Pins that a configuration whose
+    register-table layout still exceeds LDS falls back to the global table WITH the full [row][t] entry count -- the
+    kernels of that fallback index cap * (N + 1) rows of the workspace."""
+    cfg = nm.default_config_struct()
+    li = nm.layout_info(cfg)
+    assert li.np == 2778 and li.reg_slots_f32 == 14 and not li.global_table_f32 and li.table_entries_f32 == 15 + 1
+    cfg.max_active_dynobs = 10
+    assert nm.layout_info(cfg).reg_slots_f32 == 4
+    cfg = nm.default_config_struct()
+    cfg.N_hor, cfg.Ndynobs = 40, 160                    # BASELINE configs[4]: 236 KB table -> global workspace
+    li = nm.layout_info(cfg)
+    assert li.np == 40968 and li.global_table_f32 and li.global_table_f64 and li.reg_slots_f32 == 0
+    assert li.ws_elems_f32 == 9 * 160 * 41 == li.ws_elems_f64 and li.table_entries_f32 == 160 * 41
+    # register table selected (<= 42 rows, N <= 21) but everything else does not fit LDS: so many static obstacles that
+    # the polygon table alone is ~160 KB in fp32
+    cfg = nm.default_config_struct()
+    cfg.Nstcobs = 3300
+    li = nm.layout_info(cfg)
+    assert li.global_table_f32 and li.reg_slots_f32 == 0
+    assert li.table_entries_f32 == 15 * 21 and li.ws_elems_f32 == 9 * 15 * 21
+    cfg.N_hor = 0
+    with pytest.raises(nm.NmpcError):
+        nm.layout_info(cfg)

@@ -1,0 +1,183 @@
+"""Round-3 kernel features, all through the C ABI:
+
+* the axis-aligned variant of the register-table kernels (nmpc_config.axis_aligned) and the device-side choice between
+  it and the general kernel (twin launch) -- psi / grad psi against the oracle, against the general kernel, and the
+  broken-promise status;
+* the resumable two-launch solve (nmpc_config.staged) -- bit-identical to the one-launch solve;
+* the fp64 continuation (nmpc_config.polish) -- lands on the tight-tolerance fixed point, leaves everything else alone.
+"""
+import numpy as np
+import pytest
+
+import dyobav_mpcnwta_warehouse_amd as nm
+import oracle
+from dyobav_mpcnwta_warehouse_amd.scenarios import ParamLayout
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(lay, n_active=0, **ov):
+    cfg = nm.default_config_struct()
+    cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs = lay.N, lay.Nother, lay.Nstc, lay.Ndyn
+    cfg.max_active_dynobs = n_active
+    for k, v in ov.items():
+        assert hasattr(cfg, k), k
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _on_path_batch(lay, B, seed, n_ped, n_hyp, rotate=False):
+    """pedestrians ON the robot's path (soft and hard ellipse terms active), unequal radii; `rotate`: angles != 0"""
+    P = nm.scenarios.make_batch(B, lay, seed=seed, n_ped=n_ped, n_hyp=n_hyp, ped_mode="oncoming")
+    rng = np.random.default_rng(seed + 1)
+    od = P[:, lay.od:lay.od + 6 * (lay.N + 1) * lay.Ndyn].reshape(B, lay.Ndyn, lay.N + 1, 6)
+    act = np.abs(od[..., 2]).sum(axis=2) > 0
+    od[..., 3] *= rng.uniform(0.6, 1.6, od[..., 3].shape)            # rx != ry
+    if rotate:
+        od[..., 4] = np.where(act[..., None], rng.uniform(-1.2, 1.2, od[..., 4].shape), 0.0)
+    return P
+
+
+@pytest.mark.parametrize("n_ped,n_hyp,slots", [(2, 5, 4), (4, 10, 14), (1, 1, 4), (7, 6, 14)])
+def test_axis_aligned_variant_against_oracle_and_general_kernel(n_ped, n_hyp, slots):
+    lay = ParamLayout(N=20, Ndyn=max(15, n_ped * n_hyp))
+    B = 24
+    P = _on_path_batch(lay, B, 5, n_ped, n_hyp)
+    assert nm.layout_info(_cfg(lay, n_ped * n_hyp)).reg_slots_f32 == slots
+    pr = oracle.Problem(lay.N, lay.Nother, lay.Nstc, lay.Ndyn)
+    rng = np.random.default_rng(0)
+    U = np.stack([rng.uniform(0.3, 1.4, (B, lay.N)), rng.uniform(-0.3, 0.3, (B, lay.N))], axis=2).reshape(B, -1)
+    Y, C = rng.normal(size=(B, 2 * lay.N)), rng.uniform(1, 300, B)
+    P32, U32, Y32, C32 = (a.astype(np.float32) for a in (P, U, Y, C))
+    res = {}
+    for mode in (-1, 0, 1):
+        with nm.Handle(_cfg(lay, n_ped * n_hyp, axis_aligned=mode, latency_waves=1)) as h:
+            res[mode] = h.eval(P32, U32, Y32, C32, dtype=np.float32)
+            assert h.last_launch_info()["axis_aligned"] == {-1: 0, 0: 2, 1: 1}[mode]
+    nz = 0
+    for i in range(B):
+        v, g = oracle.psi(pr, U32[i].astype(np.float64), float(C32[i]), Y32[i].astype(np.float64), P32[i].astype(np.float64))
+        f2 = float(np.sum(np.asarray(oracle.eval_problem(pr, U32[i].astype(np.float64), P32[i].astype(np.float64))[2]) ** 2))
+        nz += f2 > 0
+        for mode in (-1, 0, 1):
+            r = res[mode]
+            assert abs(r["psi"][i] - v) <= 2e-5 * max(1.0, abs(v)), (mode, i)
+            assert np.abs(r["grad"][i] - g).max() <= 3e-4 * max(1.0, np.abs(g).max()), (mode, i)
+            assert abs(r["f2sq"][i] - f2) <= 1e-4 * max(1.0, f2), (mode, i)
+    assert nz >= B // 4                                  # the hard-ellipse sums were in play
+    # automatic = the promised variant (the same kernel ran); and on axis-aligned input the general kernel only adds and
+    # multiplies exact zeros on top of it: bit-identical
+    for k in ("psi", "grad", "f2sq"):
+        assert np.array_equal(res[0][k], res[1][k]), k
+        assert np.array_equal(res[0][k], res[-1][k]), k
+
+
+def test_rotated_ellipses_take_the_general_kernel_and_break_the_promise():
+    lay = ParamLayout(N=20, Ndyn=15)
+    B = 16
+    P = _on_path_batch(lay, B, 6, 2, 5, rotate=True).astype(np.float32)
+    P[: B // 2] = _on_path_batch(lay, B, 6, 2, 5)[: B // 2].astype(np.float32)   # first half axis-aligned
+    out = {}
+    for mode in (-1, 0, 1):
+        cfg = _cfg(lay, 10, axis_aligned=mode, latency_waves=1, max_outer_iterations=2, max_inner_iterations=20)
+        with nm.Handle(cfg) as h:
+            out[mode] = h.solve(P)
+    # one skewed ellipse anywhere in the batch: the scan sends the WHOLE batch to the general kernel
+    for k in ("U", "status", "iters", "cost"):
+        assert np.array_equal(out[0][k], out[-1][k]), k
+    with nm.Handle(_cfg(lay, 10, latency_waves=1, max_outer_iterations=2, max_inner_iterations=20)) as h:
+        half = h.solve(P[: B // 2])                    # without the skewed half: the axis-aligned kernel, same numbers
+        assert h.last_launch_info()["axis_aligned"] == 2
+    assert np.array_equal(half["U"], out[-1]["U"][: B // 2]) and np.array_equal(half["iters"], out[-1]["iters"][: B // 2])
+    # promised: the axis-aligned half is solved, the rest is refused
+    assert (out[1]["status"][B // 2:] == 5).all() and np.isnan(out[1]["U"][B // 2:]).all()
+    assert (out[1]["status"][: B // 2] <= 1).all()
+    assert np.abs(out[1]["U"][: B // 2] - out[-1]["U"][: B // 2]).max() < 5e-3
+
+
+@pytest.mark.parametrize("dtype,ov", [(np.float32, {}), (np.float32, {"reg_table": -1}), (np.float64, {}),
+                                      (np.float32, {"axis_aligned": -1})])
+def test_staged_solve_is_bit_identical_to_the_one_launch_solve(dtype, ov):
+    lay = ParamLayout(N=20, Ndyn=40)
+    B = 1536
+    P = nm.scenarios.make_batch(B, lay, seed=3, n_ped=4, n_hyp=10, ped_mode="passing").astype(dtype)
+    base = None
+    for staged in (-1, 1, 2, 4):
+        with nm.Handle(_cfg(lay, 40, staged=staged, latency_waves=1, coop_waves=1, **ov)) as h:
+            r = h.solve(P)
+        if base is None:
+            base = r
+            assert (r["iters"][:, 0] > 4).sum() > B // 10       # instances that cross every stage boundary
+            continue
+        for k in ("U", "cost", "status", "iters", "y", "info"):
+            assert np.array_equal(r[k], base[k]), (staged, k)
+
+
+def test_staged_solve_other_dimensions_and_automatic_choice():
+    # N = 40 (one lane per step, obstacle table in the global workspace), N = 30 (two lanes per step)
+    for N, Ndyn, B in ((40, 160, 48), (30, 12, 96)):
+        lay = ParamLayout(N=N, Ndyn=Ndyn)
+        P = nm.scenarios.make_batch(B, lay, seed=4, n_ped=2, n_hyp=3, ped_mode="oncoming")
+        for dtype in (np.float32, np.float64):
+            a, b = (None, None)
+            for staged in (-1, 2):
+                cfg = _cfg(lay, 0, staged=staged, latency_waves=1, coop_waves=1, max_inner_iterations=60, max_outer_iterations=5)
+                with nm.Handle(cfg) as h:
+                    r = h.solve(P.astype(dtype))
+                a, b = (r, b) if staged < 0 else (a, r)
+            for k in ("U", "cost", "status", "iters", "y", "info"):
+                assert np.array_equal(a[k], b[k]), (N, dtype, k)
+    # automatic: on for a batch that fills the device several times over, and still the same numbers
+    lay = ParamLayout(N=20, Ndyn=15)
+    P = nm.scenarios.make_batch(16384, lay, seed=5, n_ped=0, n_boxes=0).astype(np.float32)
+    with nm.Handle(_cfg(lay, 0, staged=0)) as h:
+        auto = h.solve(P)
+    with nm.Handle(_cfg(lay, 0, staged=-1)) as h:
+        one = h.solve(P)
+    for k in ("U", "status", "iters"):
+        assert np.array_equal(auto[k], one[k]), k
+
+
+def test_polish_reaches_the_tight_fixed_point_and_touches_nothing_else():
+    lay = ParamLayout(N=20, Ndyn=15)
+    B = 192
+    P = nm.scenarios.make_batch(B, lay, seed=1234, n_ped=2, n_hyp=5, ped_mode="passing")
+    P32 = P.astype(np.float32)
+    with nm.Handle(_cfg(lay, 10)) as h:
+        plain = h.solve(P32)
+    with nm.Handle(_cfg(lay, 10, polish=1)) as h:
+        pol = h.solve(P32)
+        pol_min = {}                                              # optional outputs left out: same controls
+        U = np.empty((B, 2 * lay.N), np.float32)
+        h.solve_raw(np.float32, P32, B, U)
+        pol_min["U"] = U
+    with nm.Handle(_cfg(lay, 10, tolerance=1e-8, initial_tolerance=1e-8, delta_tolerance=1e-8, max_inner_iterations=2000,
+                        max_outer_iterations=15)) as h:
+        tight = h.solve(P, dtype=np.float64)
+    assert np.array_equal(pol_min["U"], pol["U"])
+    assert np.array_equal(pol["status"], plain["status"])        # polish never changes an exit status
+    flag = pol["info"][:, 6]
+    sel = plain["status"] == 0
+    assert sel.sum() >= B // 4 and (flag[~sel] == 0).all() and (flag[sel] >= 1).all()
+    for k in ("U", "cost", "y"):                                 # not selected, or continuation not converged: untouched
+        assert np.array_equal(pol[k][flag != 1], plain[k][flag != 1]), k
+    assert np.array_equal(pol["iters"][flag == 0], plain["iters"][flag == 0])
+    assert (pol["iters"][flag == 2, 1] > plain["iters"][flag == 2, 1]).all()      # (the work done is counted either way)
+    done = flag == 1
+    assert done.sum() >= 0.6 * sel.sum()
+    assert (pol["iters"][done, 1] > plain["iters"][done, 1]).all()
+    both = done & (tight["status"] == 0)
+    du = np.abs(pol["U"].astype(np.float64) - tight["U"]).max(axis=1)
+    du_plain = np.abs(plain["U"].astype(np.float64) - tight["U"]).max(axis=1)
+    print(f"polished {done.sum()} of {sel.sum()} converged; vs fp64 at 1e-8: median {np.median(du[both]):.2e} "
+          f"(unpolished {np.median(du_plain[both]):.2e}), < 1e-4: {np.mean(du[both] < 1e-4):.2f}")
+    assert both.sum() >= 20 and np.median(du[both]) < 1e-4 and np.mean(du[both] < 1e-4) >= 0.7
+    assert np.median(du_plain[both]) > 3e-4                      # (what the default tolerance alone locates)
+    # fp64 main solve + polish: same mechanism
+    with nm.Handle(_cfg(lay, 10, polish=1)) as h:
+        pol64 = h.solve(P, dtype=np.float64)
+    d64 = (pol64["info"][:, 6] == 1) & done
+    assert d64.sum() >= 20
+    dd = np.abs(pol64["U"] - pol["U"].astype(np.float64)).max(axis=1)[d64]
+    print(f"fp32+polish vs fp64+polish: median {np.median(dd):.2e}, < 1e-4: {np.mean(dd < 1e-4):.2f}")
+    assert np.median(dd) < 1e-4 and np.mean(dd < 1e-4) >= 0.7
