@@ -7,7 +7,9 @@ bench.py reports as `accuracy`; the assertions pin what the protocol establishes
     sides coincide to solver accuracy in the median (fp64: 1e-6);
   * tightened tolerance (1e-8, family `passing`): instances converged on both sides coincide to 1e-4 in the median -- the north-star
     bar is met where the comparison is well-posed (the minimiser is located to 1e-8, not to tol/gamma);
-  * fp32 vs fp64 at the default tolerance: the documented ~1e-3 ... 1e-2 (error ~ tol/gamma), asserted < 5e-2.
+  * fp32 vs fp64 at the default tolerance: the documented ~1e-3 ... 1e-2 (error ~ tol/gamma), asserted < 5e-2;
+  * fp32 + fp64 polish (nmpc_config.polish) vs fp64 + polish and vs the fp64 fixed point: median below the north
+    star's 1e-4.
 """
 import json
 
@@ -36,7 +38,18 @@ def test_accuracy_protocol(workload, family, n):
         assert a["median_abs_du_both_converged"] < (1e-6 if workload != "cfg4" else 1e-2), a
         assert t["both_converged"] >= 3 and t["median_abs_du_both_converged"] < 1e-4, t
         assert t["frac_lt_1e-4_both_converged"] >= 0.5, t
+        # fp32 against fp64 at the DEFAULT tolerance is only as close as that tolerance pins u (~1e-3, printed above);
+        # with the fp64 continuation of the converged instances (nmpc_config.polish) the headline dtype meets the
+        # north star's 1e-4 -- against fp64 + the same continuation and against the fp64 fixed point (tolerance 1e-8)
         assert f["both_converged"] >= 3 and f["median_abs_du_both_converged"] < 5e-2, f
+        pp = row["hip32polish_vs_hip64polish"]
+        # (N = 40: twice the lever arm, the polish's default tolerance of 1e-6 pins u to ~3e-4 there; polish_tolerance is
+        #  a configuration field)
+        assert pp["n"] >= 3 and pp["median_abs_du"] < (1e-4 if workload != "cfg4" else 1e-3), pp
+        if workload != "cfg4":
+            pt, dt = row["hip32polish_vs_hip64_tight"], row["hip64_vs_hip64_tight"]
+            assert pt["n"] >= 5 and pt["median_abs_du"] < 1e-4 and pt["frac_lt_1e-4"] >= 0.7, pt
+            assert dt["median_abs_du"] > 3e-4, dt          # (what the default tolerance alone locates, fp64 included)
     else:                                      # contract family: almost nothing converges; the runs must still agree
         assert abs(row["converged_frac"]["hip64"] - row["converged_frac"]["oracle64"]) <= 0.1
         assert np.isfinite(a["median_abs_du_all"])
@@ -51,7 +64,8 @@ def test_tight_solutions_match_an_independent_nlp_solver():
     P = nm.scenarios.make_batch(12, fpi.LAY, seed=33, n_ped=0, n_boxes=0)
     ref = np.array([fpi._slsqp(p)[0] for p in P])
     # fp32: measured 2e-4 median / 5e-4 worst converged instance at tolerance 1e-5 -- its stated tolerance is 1e-3
-    for dtype, tol, bound, med in ((np.float64, 1e-8, 1e-4, 5e-6), (np.float32, 1e-5, 1e-3, 5e-4)):
+    # fp32 + polish: the DEFAULT fp32 solve, its converged instances continued in fp64 at tolerance 1e-7 -- 1e-4 like fp64
+    for dtype, tol, bound, med in ((np.float64, 1e-8, 1e-4, 5e-6), (np.float32, 1e-5, 1e-3, 5e-4), ("f32+polish", 1e-4, 1e-4, None)):
         for name, ov in (("throughput", dict(latency_waves=1, coop_waves=1)), ("latency", dict(latency_waves=4)),
                          ("cooperative", dict(latency_waves=1, coop_waves=4, reg_table=-1))):
             cfg = nm.default_config_struct()
@@ -60,6 +74,18 @@ def test_tight_solutions_match_an_independent_nlp_solver():
             cfg.lip_eps_f64 = cfg.lip_delta_f64 = 1e-6
             for k, v in ov.items():
                 setattr(cfg, k, v)
+            if dtype == "f32+polish":
+                cfg.max_outer_iterations, cfg.max_inner_iterations = 10, 500       # the reference's own caps
+                cfg.polish, cfg.polish_tolerance, cfg.polish_delta_tolerance = 1, 1e-7, 1e-6
+                cfg.polish_max_outer_iterations, cfg.polish_max_inner_iterations = 8, 1000
+                with nm.Handle(cfg) as h:
+                    r = h.solve(P.astype(np.float32), dtype=np.float32)
+                du = np.abs(r["U"].astype(np.float64) - ref).max(axis=1)
+                done = r["info"][:, 6] == 1
+                print(f"float32 + fp64 polish, {name}: {(r['status'] == 0).sum()}/12 converged, {done.sum()} polished, "
+                      f"max|u - u_slsqp| over the polished: median {np.median(du[done]):.2e}, max {du[done].max():.2e}")
+                assert done.sum() >= 6 and du[done].max() < bound, (name, du, r["info"][:, 6])
+                continue
             with nm.Handle(cfg) as h:
                 r = h.solve(P.astype(dtype), dtype=dtype)
             du = np.abs(r["U"].astype(np.float64) - ref).max(axis=1)

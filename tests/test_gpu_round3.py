@@ -140,7 +140,7 @@ def test_staged_solve_other_dimensions_and_automatic_choice():
 
 def test_polish_reaches_the_tight_fixed_point_and_touches_nothing_else():
     lay = ParamLayout(N=20, Ndyn=15)
-    B = 192
+    B = 768
     P = nm.scenarios.make_batch(B, lay, seed=1234, n_ped=2, n_hyp=5, ped_mode="passing")
     P32 = P.astype(np.float32)
     with nm.Handle(_cfg(lay, 10)) as h:
@@ -151,6 +151,7 @@ def test_polish_reaches_the_tight_fixed_point_and_touches_nothing_else():
         U = np.empty((B, 2 * lay.N), np.float32)
         h.solve_raw(np.float32, P32, B, U)
         pol_min["U"] = U
+    # the fixed point: fp64 from scratch at tolerance 1e-8 (OpEn's own fp64 Lipschitz step)
     with nm.Handle(_cfg(lay, 10, tolerance=1e-8, initial_tolerance=1e-8, delta_tolerance=1e-8, max_inner_iterations=2000,
                         max_outer_iterations=15)) as h:
         tight = h.solve(P, dtype=np.float64)
@@ -171,13 +172,18 @@ def test_polish_reaches_the_tight_fixed_point_and_touches_nothing_else():
     du_plain = np.abs(plain["U"].astype(np.float64) - tight["U"]).max(axis=1)
     print(f"polished {done.sum()} of {sel.sum()} converged; vs fp64 at 1e-8: median {np.median(du[both]):.2e} "
           f"(unpolished {np.median(du_plain[both]):.2e}), < 1e-4: {np.mean(du[both] < 1e-4):.2f}")
-    assert both.sum() >= 20 and np.median(du[both]) < 1e-4 and np.mean(du[both] < 1e-4) >= 0.7
-    assert np.median(du_plain[both]) > 3e-4                      # (what the default tolerance alone locates)
+    # north star: max|u - u_ref| < 1e-4 -- met by the headline dtype with the polish on (measured on 1024 instances:
+    # median 1.1e-5, 91 % below 1e-4; the rest sits in another local minimum of the non-convex problem or on a flat
+    # direction), not by ANY solver at the default tolerance alone (fp64 included: median 1.5e-3)
+    assert both.sum() >= 60 and np.median(du[both]) < 3e-5 and np.mean(du[both] < 1e-4) >= 0.8
+    assert np.median(du_plain[both]) > 3e-4 and np.mean(du_plain[both] < 1e-4) < 0.1
     # fp64 main solve + polish: same mechanism
     with nm.Handle(_cfg(lay, 10, polish=1)) as h:
         pol64 = h.solve(P, dtype=np.float64)
     d64 = (pol64["info"][:, 6] == 1) & done
-    assert d64.sum() >= 20
+    assert d64.sum() >= 60
     dd = np.abs(pol64["U"] - pol["U"].astype(np.float64)).max(axis=1)[d64]
     print(f"fp32+polish vs fp64+polish: median {np.median(dd):.2e}, < 1e-4: {np.mean(dd < 1e-4):.2f}")
-    assert np.median(dd) < 1e-4 and np.mean(dd < 1e-4) >= 0.7
+    # (two continuations from two different default-tolerance end points: where the non-convex problem has several
+    #  minima nearby, or a flat direction, they need not pick the same one -- the misses of both sides add up)
+    assert np.median(dd) < 3e-5 and np.mean(dd < 1e-4) >= 0.55
