@@ -67,6 +67,17 @@ class NmpcAssembleArgs(C.Structure):
                 ("stc_weights", C.c_void_p), ("dyn_weights", C.c_void_p), ("selected", C.c_void_p)]
 
 
+class NmpcLoopArgs(C.Structure):
+    """Mirror of ``struct nmpc_loop_args`` (device pointers)."""
+    _fields_ = ([(n, C.c_int32) for n in ("B", "n_run", "H", "W", "Lmax", "M", "step", "max_steps")] + [("run", C.c_void_p)] +
+                [(n, C.c_double) for n in ("base_speed", "lin_vel_max", "human_size", "human_vmax")] +
+                [(n, C.c_void_p) for n in ("robot", "last_u", "humans", "hist", "hcount", "hidx", "hpath", "ref_traj", "ref_len",
+                                           "idx_ref", "goal", "polys", "stagger", "alive", "collision", "complete", "steps",
+                                           "clr_dyn", "clr_stc", "dev_sum", "dev_max", "n_traj", "traj", "acts", "state_c",
+                                           "last_u_c", "refs_c", "speed_c", "dyn_c", "U_c", "y_c", "U", "y")] +
+                [("gather_y", C.c_int32), ("reserved", C.c_int32)])
+
+
 # every symbol include/nmpc_hip.h declares (checked by the CPU test-suite against the built library)
 EXPORTED_SYMBOLS = (
     "nmpc_default_config", "nmpc_layout", "nmpc_create", "nmpc_destroy", "nmpc_param_len", "nmpc_set_stream", "nmpc_use_own_stream", "nmpc_set_pointer_mode",
@@ -74,6 +85,7 @@ EXPORTED_SYMBOLS = (
     "nmpc_solve_batch_f32", "nmpc_solve_batch_f64", "nmpc_eval_batch_f32", "nmpc_eval_batch_f64",
     "nmpc_assemble_params_f32", "nmpc_assemble_params_f64",
     "nmpc_hypotheses_to_ellipses_f32", "nmpc_hypotheses_to_ellipses_f64",
+    "nmpc_loop_pre_f32", "nmpc_loop_pre_f64", "nmpc_loop_post_f32", "nmpc_loop_post_f64",
     "nmpc_last_kernel_ms", "nmpc_last_launch_info", "nmpc_kernel_info", "nmpc_selftest", "nmpc_last_error",
 )
 
@@ -120,6 +132,8 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
         getattr(lib, "nmpc_assemble_params_" + sfx).argtypes = [vp, C.POINTER(NmpcAssembleArgs), i32, vp]
         getattr(lib, "nmpc_hypotheses_to_ellipses_" + sfx).argtypes = [vp, vp, i32, vp, i32, C.c_double, C.c_double,
                                                                        C.c_double, C.c_double, i32, vp, vp]
+        getattr(lib, "nmpc_loop_pre_" + sfx).argtypes = [vp, C.POINTER(NmpcLoopArgs)]
+        getattr(lib, "nmpc_loop_post_" + sfx).argtypes = [vp, C.POINTER(NmpcLoopArgs)]
     lib.nmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.nmpc_kernel_info.argtypes = [vp] + [C.POINTER(i32)] * 5
     lib.nmpc_last_launch_info.argtypes = [vp, C.POINTER(i32 * 8)]
@@ -279,6 +293,12 @@ class Handle:
         a.selected = p(selected)
         fn = getattr(self._lib, "nmpc_assemble_params_" + _suffix(dtype))
         _check(fn(self._h, C.byref(a), int(B), p(P_out)))
+
+    def loop_step(self, dtype, args: "NmpcLoopArgs", post: bool):
+        """``nmpc_loop_pre_*`` / ``nmpc_loop_post_*``: one half of a closed-loop time step (row f3), enqueued on the
+        handle's stream."""
+        fn = getattr(self._lib, ("nmpc_loop_post_" if post else "nmpc_loop_pre_") + _suffix(dtype))
+        _check(fn(self._h, C.byref(args)))
 
     def hypotheses_to_ellipses(self, dtype, hypos, cur, dyn_out, n_obs_out=None, human_size=0.2, eps=1.0, enlarge=2.0,
                                extra_margin=0.0):

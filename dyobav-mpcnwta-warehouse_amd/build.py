@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 # NMPC_HIP_LIBRARY: load an alternative build of the same C ABI (A/B tests of kernel variants)
 LIB_PATH = os.environ.get("NMPC_HIP_LIBRARY") or os.path.join(PKG_DIR, "libnmpc_hip.so")
 SOURCES = ("nmpc_capi.hip",)
-HEADERS = ("nmpc_device.h", "nmpc_spec.h", "nmpc_assemble.h", "nmpc_hypotheses.h", "wave_ops.h", os.path.join("..", "..", "include", "nmpc_hip.h"))
+HEADERS = ("nmpc_device.h", "nmpc_spec.h", "nmpc_assemble.h", "nmpc_hypotheses.h", "nmpc_step.h", "wave_ops.h", os.path.join("..", "..", "include", "nmpc_hip.h"))
 # -fno-slp-vectorize: packed fp32 VALU ops (v_pk_fma_f32 ...) issue at half the rate of plain ones on gfx950 (measured,
 # tools/mb/issue_rate.hip), so they buy nothing once two wavefronts share a SIMD, but they need their operands in aligned
 # register pairs -- with the register-resident obstacle table that costs ~40 VGPRs in copies and the second wavefront.

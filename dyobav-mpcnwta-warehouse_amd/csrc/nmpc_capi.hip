@@ -17,6 +17,7 @@
 #include "nmpc_device.h"
 #include "nmpc_spec.h"
 #include "nmpc_hypotheses.h"
+#include "nmpc_step.h"
 
 namespace {
 
@@ -204,7 +205,8 @@ struct nmpc_handle_s {
     DevBuf dP, dU, dcost, dstatus, diters, du0, dy, dc0, dinfo, dY2, dC2, dpsi, dgrad, df2, dws;
     DevBuf dorder;   // dispatch order of the next solves (nmpc_set_dispatch_order), order_B entries; 0 = none
     int order_B = 0;
-    DevBuf dflag;    // device flags of the twin launches ([0]: some ellipse of the batch is not axis-aligned)
+    DevBuf dflag;    // [0]: epoch of the last call whose batch had an ellipse with angle != 0 (KParams::axis_flag)
+    int axis_epoch = 0;
     DevBuf dresume, dorder2, dhist; // resumable solve: parked states, ranked order of the second launch, bucket counters
     // polish: compact fp64 copies of the selected instances and their results
     DevBuf psel, pP, pU0, pY, pC, pU, pcost, pstatus, piters, pinfo;
@@ -226,13 +228,22 @@ constexpr int wpe(int f32_default)
 {
     return sizeof(T) == 8 ? NMPC_WPE_F64 : RS >= kRegSlotsLarge ? 2 : RS > 0 ? 3 : f32_default;
 }
-template <typename T, int LPS, bool GLB, int RS = 0, bool AXIS = false>
+// (register-table kernels: the general and the axis-aligned variant in one kernel, see KParams::axis_mode)
+template <typename T, int LPS, int RS>
+constexpr bool kHasAxisVariant = sizeof(T) == 4 && LPS == 3 && RS > 0;
+
+template <typename T, int LPS, bool GLB, int RS = 0>
 __global__ __launch_bounds__(64, (wpe<T, RS>(NMPC_WPE_F32))) void solve_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int inst = nmpc::dispatch_index(kp);
-    if (inst < 0) return;
-    nmpc::solve_instance<T, LPS, GLB, RS, false, false, AXIS>(kp, inst, reinterpret_cast<T*>(smem));
+    if constexpr (kHasAxisVariant<T, LPS, RS> && !GLB) {
+        if (nmpc::axis_path(kp)) {
+            nmpc::solve_instance<T, LPS, GLB, RS, false, false, true>(kp, inst, reinterpret_cast<T*>(smem));
+            return;
+        }
+    }
+    nmpc::solve_instance<T, LPS, GLB, RS>(kp, inst, reinterpret_cast<T*>(smem));
 }
 
 // cooperative mode: up to kSpecWaves wavefronts per instance share every evaluation (nmpc_device.h, COOP)
@@ -241,7 +252,6 @@ __global__ __launch_bounds__(64 * kSpecWaves, (sizeof(T) == 4 ? NMPC_SPEC_WPE_F3
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int inst = nmpc::dispatch_index(kp);
-    if (inst < 0) return;
     nmpc::solve_instance<T, LPS, GLB, 0, true>(kp, inst, reinterpret_cast<T*>(smem));
 }
 // ... with the obstacle table on chip instead of in global memory, for one lane per horizon step (N > 32), where it does
@@ -251,27 +261,29 @@ __global__ __launch_bounds__(64 * kCoopRegWaves, 2) void solve_coop_reg_kernel(n
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int inst = nmpc::dispatch_index(kp);
-    if (inst < 0) return;
     nmpc::solve_instance<float, 1, false, kRegSlotsCoop, true, HLP>(kp, inst, reinterpret_cast<float*>(smem));
 }
 
 // latency mode: kSpecWaves wavefronts per instance, speculative line search (nmpc_spec.h)
-template <typename T, int LPS, bool GLB, int RS = 0, bool AXIS = false>
+template <typename T, int LPS, bool GLB, int RS = 0>
 __global__ __launch_bounds__(64 * kSpecWaves, (wpe<T, RS>(NMPC_SPEC_WPE_F32))) void solve_spec_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int inst = nmpc::dispatch_index(kp);
-    if (inst < 0) return;
-    nmpc::solve_instance_spec<T, LPS, GLB, RS, AXIS>(kp, inst, reinterpret_cast<T*>(smem));
+    if constexpr (kHasAxisVariant<T, LPS, RS> && !GLB) {
+        if (nmpc::axis_path(kp)) {
+            nmpc::solve_instance_spec<T, LPS, GLB, RS, true>(kp, inst, reinterpret_cast<T*>(smem));
+            return;
+        }
+    }
+    nmpc::solve_instance_spec<T, LPS, GLB, RS>(kp, inst, reinterpret_cast<T*>(smem));
 }
 
-template <typename T, int LPS, bool GLB, int RS = 0, bool AXIS = false>
-__global__ __launch_bounds__(64) void eval_kernel(nmpc::KParams<T> kp, nmpc::EvalParams<T> ep)
+template <typename T, int LPS, bool GLB, int RS, bool AXIS>
+__device__ __forceinline__ void eval_instance(const nmpc::KParams<T>& kp, const nmpc::EvalParams<T>& ep, T* lds)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (nmpc::dispatch_index(kp) < 0) return; // (twin launch of the other variant)
     const int inst = blockIdx.x, N = kp.N;
-    nmpc::Instance<T, LPS, GLB, RS, false, false, AXIS> I(kp, kp.P + (size_t)inst * kp.np, reinterpret_cast<T*>(smem),
+    nmpc::Instance<T, LPS, GLB, RS, false, false, AXIS> I(kp, kp.P + (size_t)inst * kp.np, lds,
                                                         GLB ? kp.ws + (long long)inst * kp.ws_stride : nullptr);
     if (I.load()) {
         if (I.lane == 0) ep.psi[inst] = __builtin_nanf("");
@@ -297,17 +309,29 @@ __global__ __launch_bounds__(64) void eval_kernel(nmpc::KParams<T> kp, nmpc::Eva
         if (ep.f2sq) ep.f2sq[inst] = f2;
     }
 }
+template <typename T, int LPS, bool GLB, int RS = 0>
+__global__ __launch_bounds__(64) void eval_kernel(nmpc::KParams<T> kp, nmpc::EvalParams<T> ep)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if constexpr (kHasAxisVariant<T, LPS, RS> && !GLB) {
+        if (nmpc::axis_path(kp)) {
+            eval_instance<T, LPS, GLB, RS, true>(kp, ep, reinterpret_cast<T*>(smem));
+            return;
+        }
+    }
+    eval_instance<T, LPS, GLB, RS, false>(kp, ep, reinterpret_cast<T*>(smem));
+}
 
 // ---- small data kernels around the solves ------------------------------------------------------------------------
-// Is some ellipse of the batch not axis-aligned (angle != 0)? One workgroup per instance over o_d[j][t][4]; *flag is
-// zeroed before the launch, any workgroup that finds a non-zero angle stores 1 (plain store: all writers agree).
+// Is some ellipse of the batch not axis-aligned (angle != 0)? One workgroup per instance over o_d[j][t][4]; any
+// workgroup that finds a non-zero angle stores the call's epoch in *flag (plain store: all writers agree).
 template <typename T>
-__global__ __launch_bounds__(256) void axis_scan_kernel(const T* P, int np, int off_od, int n_entries, int* flag)
+__global__ __launch_bounds__(256) void axis_scan_kernel(const T* P, int np, int off_od, int n_entries, int* flag, int epoch)
 {
     const T* s = P + (size_t)blockIdx.x * np + off_od;
     bool skew = false;
     for (int e = threadIdx.x; e < n_entries; e += 256) skew = skew || s[6 * e + 4] != T(0);
-    if (skew) *flag = 1;
+    if (skew) *flag = epoch; // (this call's epoch: the flag needs no reset between calls)
 }
 
 // Resumable solve, ranking of the second launch: bucket = the top 10 bits of ||F2|| (as float; monotonic for values
@@ -560,31 +584,24 @@ void (*pick_solve_coop_reg(int N))(nmpc::KParams<float>)
     return coop_helper_lanes(N) ? solve_coop_reg_kernel<true> : solve_coop_reg_kernel<false>;
 }
 
-// (the register-table variants exist for float with three lanes per step only; `axis`: their axis-aligned twins, null
-//  where there is none)
+// (the register-table variants exist for float with three lanes per step only)
 template <typename T>
-SolveFn<T> pick_solve(int lps, bool glb, int rs = 0, bool axis = false)
+SolveFn<T> pick_solve(int lps, bool glb, int rs = 0)
 {
     if constexpr (sizeof(T) == 4) {
-        if (rs == kRegSlotsSmall && lps == 3 && !glb)
-            return axis ? solve_kernel<T, 3, false, kRegSlotsSmall, true> : solve_kernel<T, 3, false, kRegSlotsSmall>;
-        if (rs == kRegSlotsLarge && lps == 3 && !glb)
-            return axis ? solve_kernel<T, 3, false, kRegSlotsLarge, true> : solve_kernel<T, 3, false, kRegSlotsLarge>;
+        if (rs == kRegSlotsSmall && lps == 3 && !glb) return solve_kernel<T, 3, false, kRegSlotsSmall>;
+        if (rs == kRegSlotsLarge && lps == 3 && !glb) return solve_kernel<T, 3, false, kRegSlotsLarge>;
     }
-    if (axis) return nullptr;
     if (glb) return lps == 3 ? solve_kernel<T, 3, true> : lps == 2 ? solve_kernel<T, 2, true> : solve_kernel<T, 1, true>;
     return lps == 3 ? solve_kernel<T, 3, false> : lps == 2 ? solve_kernel<T, 2, false> : solve_kernel<T, 1, false>;
 }
 template <typename T>
-SolveFn<T> pick_solve_spec(int lps, bool glb, int rs = 0, bool axis = false)
+SolveFn<T> pick_solve_spec(int lps, bool glb, int rs = 0)
 {
     if constexpr (sizeof(T) == 4) {
-        if (rs == kRegSlotsSmall && lps == 3 && !glb)
-            return axis ? solve_spec_kernel<T, 3, false, kRegSlotsSmall, true> : solve_spec_kernel<T, 3, false, kRegSlotsSmall>;
-        if (rs == kRegSlotsLarge && lps == 3 && !glb)
-            return axis ? solve_spec_kernel<T, 3, false, kRegSlotsLarge, true> : solve_spec_kernel<T, 3, false, kRegSlotsLarge>;
+        if (rs == kRegSlotsSmall && lps == 3 && !glb) return solve_spec_kernel<T, 3, false, kRegSlotsSmall>;
+        if (rs == kRegSlotsLarge && lps == 3 && !glb) return solve_spec_kernel<T, 3, false, kRegSlotsLarge>;
     }
-    if (axis) return nullptr;
     if (glb) return lps == 3 ? solve_spec_kernel<T, 3, true> : lps == 2 ? solve_spec_kernel<T, 2, true> : solve_spec_kernel<T, 1, true>;
     return lps == 3 ? solve_spec_kernel<T, 3, false> : lps == 2 ? solve_spec_kernel<T, 2, false> : solve_spec_kernel<T, 1, false>;
 }
@@ -597,15 +614,12 @@ SolveFn<T> pick_solve_coop(int lps, bool glb)
 }
 
 template <typename T>
-EvalFn<T> pick_eval(int lps, bool glb, int rs = 0, bool axis = false)
+EvalFn<T> pick_eval(int lps, bool glb, int rs = 0)
 {
     if constexpr (sizeof(T) == 4) {
-        if (rs == kRegSlotsSmall && lps == 3 && !glb)
-            return axis ? eval_kernel<T, 3, false, kRegSlotsSmall, true> : eval_kernel<T, 3, false, kRegSlotsSmall>;
-        if (rs == kRegSlotsLarge && lps == 3 && !glb)
-            return axis ? eval_kernel<T, 3, false, kRegSlotsLarge, true> : eval_kernel<T, 3, false, kRegSlotsLarge>;
+        if (rs == kRegSlotsSmall && lps == 3 && !glb) return eval_kernel<T, 3, false, kRegSlotsSmall>;
+        if (rs == kRegSlotsLarge && lps == 3 && !glb) return eval_kernel<T, 3, false, kRegSlotsLarge>;
     }
-    if (axis) return nullptr;
     if (glb) return lps == 3 ? eval_kernel<T, 3, true> : lps == 2 ? eval_kernel<T, 2, true> : eval_kernel<T, 1, true>;
     return lps == 3 ? eval_kernel<T, 3, false> : lps == 2 ? eval_kernel<T, 2, false> : eval_kernel<T, 1, false>;
 }
@@ -661,7 +675,8 @@ int stage_out(nmpc_handle_s* h, DevBuf& buf, T* dst, size_t count, T** dev, bool
 // ---- kernel choice and launch ---------------------------------------------------------------------------------------
 template <typename T>
 struct Plan {
-    SolveFn<T> fn = nullptr, fn_axis = nullptr; // fn_axis: the axis-aligned twin (null = none)
+    SolveFn<T> fn = nullptr;
+    bool has_axis = false; // the kernel contains the axis-aligned variant (KParams::axis_mode)
     int threads = 64;
     size_t lds_bytes = 0;
     int mode = 0;          // 0 throughput, 1 latency (speculative), 2 cooperative
@@ -719,11 +734,11 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
     if (L.rs > 0 || h->cfg.max_solver_time_us > 0 || !h->coop_ok[sizeof(T) == 4 ? 0 : 1]) coop = 1;
     pl.lds_bytes = (size_t)(waves ? L.lds_total_spec : L.lds_total) * sizeof(T);
     pl.fn = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs) : pick_solve<T>(h->lps, L.glb, L.rs);
-    pl.fn_axis = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs, true) : pick_solve<T>(h->lps, L.glb, L.rs, true);
+    pl.has_axis = sizeof(T) == 4 && L.rs > 0 && h->lps == 3 && !L.glb;
     pl.uses_ws = L.glb;
     if (coop > 1) {
         pl.fn = pick_solve_coop<T>(h->lps, L.glb);
-        pl.fn_axis = nullptr;
+        pl.has_axis = false;
         pl.lds_bytes = (size_t)L.lds_total_coop * sizeof(T);
         k.lds_xch = L.lds_xch_coop;
         waves = coop;
@@ -751,47 +766,37 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
     return pl;
 }
 
-// one launch of the planned kernel over `grid` workgroups; with an axis-aligned twin: `axis` = 1 the twin only, 0 the
-// general kernel only, 2 both, gated by the flag the scan of the batch left on the device
+// one launch of the planned kernel over `grid` workgroups
 template <typename T>
-int launch_plan(nmpc_handle_s* h, const Plan<T>& pl, nmpc::KParams<T> k, int grid, int axis)
+int launch_plan(nmpc_handle_s* h, const Plan<T>& pl, const nmpc::KParams<T>& k, int grid)
 {
-    if (axis != 0 && pl.fn_axis) {
-        if (axis == 2) {
-            k.gate = static_cast<const int*>(h->dflag.p);
-            k.gate_value = 0; // no skewed ellipse found
-        }
-        hipLaunchKernelGGL(pl.fn_axis, dim3(grid), dim3(pl.threads), pl.lds_bytes, h->stream, k);
-        HIP_TRY(hipGetLastError());
-        if (axis == 1) return 0;
-        k.gate_value = 1;
-    }
     hipLaunchKernelGGL(pl.fn, dim3(grid), dim3(pl.threads), pl.lds_bytes, h->stream, k);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-// Decide how the axis-aligned twins take part in a call over B instances at P (device): 0 general only, 1 twin only
-// (caller's promise), 2 decided on the device (scan enqueued here).
+// How the axis-aligned variant takes part in a call over B instances at P (device): sets k.axis_mode to 0 (general only),
+// 1 (the caller's promise) or 2 (decided on the device: the scan of the batch's angle entries is enqueued here).
 template <typename T>
-int prepare_axis(nmpc_handle_s* h, bool have_twin, const T* P, int B, int* mode)
+int prepare_axis(nmpc_handle_s* h, bool has_axis, nmpc::KParams<T>& k, int B)
 {
-    *mode = 0;
-    if (!have_twin || h->cfg.axis_aligned < 0) return 0;
+    k.axis_mode = 0;
+    if (!has_axis || h->cfg.axis_aligned < 0) return 0;
     if (h->cfg.axis_aligned > 0) {
-        *mode = 1;
+        k.axis_mode = 1;
         return 0;
     }
-    if (int rc = h->dflag.reserve(4 * sizeof(int))) return rc;
     const Layout& L = h->lay<T>();
-    HIP_TRY(hipMemsetAsync(h->dflag.p, 0, sizeof(int), h->stream));
     const int n_entries = h->cfg.Ndynobs * (h->cfg.N_hor + 1);
+    h->axis_epoch = h->axis_epoch == 0x7ffffff0 ? 1 : h->axis_epoch + 1;
+    k.axis_mode = 2;
+    k.axis_epoch = h->axis_epoch;
+    k.axis_flag = static_cast<const int*>(h->dflag.p);
     if (n_entries > 0) {
-        hipLaunchKernelGGL(axis_scan_kernel<T>, dim3(B), dim3(256), 0, h->stream, P, L.np, L.off_od, n_entries,
-                           static_cast<int*>(h->dflag.p));
+        hipLaunchKernelGGL(axis_scan_kernel<T>, dim3(B), dim3(256), 0, h->stream, k.P, L.np, L.off_od, n_entries,
+                           static_cast<int*>(h->dflag.p), h->axis_epoch);
         HIP_TRY(hipGetLastError());
     }
-    *mode = 2;
     return 0;
 }
 
@@ -810,10 +815,9 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
         k.ws = nullptr;
         k.ws_stride = 0;
     }
-    int axis = 0;
-    if (int rc = prepare_axis<T>(h, pl.fn_axis != nullptr, k.P, B, &axis)) return rc;
+    if (int rc = prepare_axis<T>(h, pl.has_axis, k, B)) return rc;
     h->last_mode = pl.mode;
-    h->last_axis = pl.fn_axis ? axis : -1;
+    h->last_axis = pl.has_axis ? k.axis_mode : -1;
     // resumable solve: automatic for batches that fill the device at least four times over with the one-wavefront kernel
     int staged = h->cfg.staged;
     if (staged == 0) {
@@ -824,7 +828,7 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
     }
     if (staged < 0 || !allow_staging || !pl.stageable || k.order || !k.status || staged >= h->cfg.max_outer_iterations) staged = 0;
     h->last_staged = staged;
-    if (staged == 0) return launch_plan<T>(h, pl, k, B, axis);
+    if (staged == 0) return launch_plan<T>(h, pl, k, B);
 
     if (int rc = h->dresume.reserve((size_t)B * nmpc::kResumeStride * sizeof(T))) return rc;
     if (int rc = h->dorder2.reserve((size_t)B * sizeof(int))) return rc;
@@ -832,7 +836,7 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
     k.resume = static_cast<T*>(h->dresume.p);
     nmpc::KParams<T> k1 = k;
     k1.stage_outer_cap = staged;
-    if (int rc = launch_plan<T>(h, pl, k1, B, axis)) return rc;
+    if (int rc = launch_plan<T>(h, pl, k1, B)) return rc;
     int* hist = static_cast<int*>(h->dhist.p);
     int* offs = hist + kRankBuckets;
     int* order2 = static_cast<int*>(h->dorder2.p);
@@ -845,7 +849,7 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
     nmpc::KParams<T> k2 = k;
     k2.stage_in = 1;
     k2.order = order2;
-    return launch_plan<T>(h, pl, k2, B, axis);
+    return launch_plan<T>(h, pl, k2, B);
 }
 
 template <typename T>
@@ -1012,14 +1016,15 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
     if ((rc = stage_out(h, h->dgrad, grad, (size_t)B * n, &ep.grad, &hgrad))) return rc;
     if ((rc = stage_out(h, h->df2, f2sq, (size_t)B, &ep.f2sq, &hf2))) return rc;
     size_t lds_bytes = (size_t)L.lds_total * sizeof(T);
-    EvalFn<T> fn = pick_eval<T>(h->lps, L.glb, L.rs), fn_axis = pick_eval<T>(h->lps, L.glb, L.rs, true);
+    EvalFn<T> fn = pick_eval<T>(h->lps, L.glb, L.rs);
+    bool has_axis = sizeof(T) == 4 && L.rs > 0 && h->lps == 3 && !L.glb;
     bool uses_ws = L.glb;
     int waves = 1;
     // coop_waves > 1: evaluate through the cooperative kernels' code path (same variant choice as solve_batch)
     if (h->cfg.coop_waves > 1 && L.rs == 0 && h->coop_ok[sizeof(T) == 4 ? 0 : 1]) {
         waves = std::min<int>(h->cfg.coop_waves, kSpecWaves);
         fn = pick_eval_coop<T>(h->lps, L.glb);
-        fn_axis = nullptr;
+        has_axis = false;
         lds_bytes = (size_t)L.lds_total_coop * sizeof(T);
         k.lds_xch = L.lds_xch_coop;
         if constexpr (sizeof(T) == 4) {
@@ -1041,27 +1046,13 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
         k.ws = static_cast<T*>(h->dws.p);
         k.ws_stride = L.ws_stride;
     }
-    int axis = 0;
-    if ((rc = prepare_axis<T>(h, fn_axis != nullptr, k.P, B, &axis))) return rc;
+    if ((rc = prepare_axis<T>(h, has_axis, k, B))) return rc;
     h->last_mode = waves > 1 ? 2 : 0;
-    h->last_axis = fn_axis ? axis : -1;
+    h->last_axis = has_axis ? k.axis_mode : -1;
     h->last_staged = 0;
     h->last_polish_selected = 0;
-    if (axis != 0 && fn_axis) {
-        nmpc::KParams<T> ka = k;
-        if (axis == 2) {
-            ka.gate = static_cast<const int*>(h->dflag.p);
-            ka.gate_value = 0;
-            k.gate = ka.gate;
-            k.gate_value = 1;
-        }
-        hipLaunchKernelGGL(fn_axis, dim3(B), dim3(64 * waves), lds_bytes, h->stream, ka, ep);
-        HIP_TRY(hipGetLastError());
-    }
-    if (axis != 1 || !fn_axis) {
-        hipLaunchKernelGGL(fn, dim3(B), dim3(64 * waves), lds_bytes, h->stream, k, ep);
-        HIP_TRY(hipGetLastError());
-    }
+    hipLaunchKernelGGL(fn, dim3(B), dim3(64 * waves), lds_bytes, h->stream, k, ep);
+    HIP_TRY(hipGetLastError());
     if (hpsi) HIP_TRY(hipMemcpyAsync(psi, ep.psi, (size_t)B * sizeof(T), hipMemcpyDeviceToHost, h->stream));
     if (hgrad) HIP_TRY(hipMemcpyAsync(grad, ep.grad, (size_t)B * n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
     if (hf2) HIP_TRY(hipMemcpyAsync(f2sq, ep.f2sq, (size_t)B * sizeof(T), hipMemcpyDeviceToHost, h->stream));
@@ -1181,6 +1172,54 @@ int hypotheses_to_ellipses(nmpc_handle_s* h, const T* hypos, int32_t P, const T*
 }
 
 template <typename T>
+int loop_step(nmpc_handle_s* h, const nmpc_loop_args* g, bool post)
+{
+    if (!h || !g) return fail(NMPC_ERR_INVALID_ARGUMENT, "null argument");
+    if (g->n_run <= 0) return g->n_run == 0 ? 0 : fail(NMPC_ERR_INVALID_ARGUMENT, "n_run < 0");
+    if (g->B < g->n_run || g->H < 1 || g->H > 64 || g->W < 1 || g->Lmax < 1 || g->M < 0 || g->step < 0 || g->step >= g->max_steps)
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_loop_*: bad dimensions (B %d, n_run %d, H %d, W %d, Lmax %d, M %d, step %d of %d)",
+                    g->B, g->n_run, g->H, g->W, g->Lmax, g->M, g->step, g->max_steps);
+    if (!g->run && g->n_run != g->B) return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_loop_*: run = NULL needs n_run = B");
+    const void* need[] = {g->robot, g->last_u, g->humans, g->hist, g->hcount, g->hidx, g->hpath, g->ref_traj, g->ref_len,
+                          g->idx_ref, g->goal, g->alive, g->collision, g->complete, g->steps, g->clr_dyn, g->clr_stc,
+                          g->dev_sum, g->dev_max, g->n_traj, g->traj, g->acts, g->state_c, g->last_u_c, g->refs_c,
+                          g->speed_c, g->dyn_c, g->U_c, g->y_c, g->U, g->y};
+    for (const void* q : need)
+        if (!q) return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_loop_*: a required array is NULL");
+    if (g->M > 0 && !g->polys) return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_loop_*: polys is NULL");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    nmpc::LoopParams<T> p;
+    std::memset(&p, 0, sizeof p);
+    p.B = g->B, p.n_run = g->n_run, p.N = h->cfg.N_hor, p.H = g->H, p.W = g->W, p.Lmax = g->Lmax, p.M = g->M;
+    p.step = g->step, p.max_steps = g->max_steps;
+    p.run = reinterpret_cast<const long long*>(g->run);
+    p.ts = (T)h->cfg.ts, p.base_speed = (T)g->base_speed, p.lin_vel_max = (T)g->lin_vel_max;
+    p.human_size = (T)g->human_size, p.human_vmax = (T)g->human_vmax;
+    p.robot = static_cast<T*>(g->robot), p.last_u = static_cast<T*>(g->last_u), p.humans = static_cast<T*>(g->humans);
+    p.hist = static_cast<T*>(g->hist);
+    p.hcount = reinterpret_cast<long long*>(g->hcount), p.hidx = reinterpret_cast<long long*>(g->hidx);
+    p.hpath = static_cast<const T*>(g->hpath), p.ref_traj = static_cast<const T*>(g->ref_traj);
+    p.ref_len = reinterpret_cast<const long long*>(g->ref_len), p.idx_ref = reinterpret_cast<long long*>(g->idx_ref);
+    p.goal = static_cast<const T*>(g->goal), p.polys = static_cast<const T*>(g->polys);
+    p.stagger = static_cast<const T*>(g->stagger);
+    p.alive = g->alive, p.collision = g->collision, p.complete = g->complete;
+    p.steps = reinterpret_cast<long long*>(g->steps);
+    p.clr_dyn = static_cast<T*>(g->clr_dyn), p.clr_stc = static_cast<T*>(g->clr_stc), p.dev_sum = static_cast<T*>(g->dev_sum);
+    p.dev_max = static_cast<T*>(g->dev_max), p.n_traj = static_cast<T*>(g->n_traj);
+    p.traj = static_cast<T*>(g->traj), p.acts = static_cast<T*>(g->acts);
+    p.state_c = static_cast<T*>(g->state_c), p.last_u_c = static_cast<T*>(g->last_u_c), p.refs_c = static_cast<T*>(g->refs_c);
+    p.speed_c = static_cast<T*>(g->speed_c), p.dyn_c = static_cast<T*>(g->dyn_c);
+    p.U_c = static_cast<T*>(g->U_c), p.y_c = static_cast<T*>(g->y_c), p.U = static_cast<T*>(g->U), p.y = static_cast<T*>(g->y);
+    p.gather_y = g->gather_y;
+    if (post)
+        hipLaunchKernelGGL(nmpc::loop_post_kernel<T>, dim3(g->n_run), dim3(64), 0, h->stream, p);
+    else
+        hipLaunchKernelGGL(nmpc::loop_pre_kernel<T>, dim3(g->n_run), dim3(64), 0, h->stream, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
 int set_lds_limit(nmpc_handle_s* h)
 {
     const Layout& L = h->lay<T>();
@@ -1190,10 +1229,6 @@ int set_lds_limit(nmpc_handle_s* h)
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_eval<T>(h->lps, L.glb, L.rs)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        if (auto f = pick_solve<T>(h->lps, L.glb, L.rs, true))
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        if (auto f = pick_eval<T>(h->lps, L.glb, L.rs, true))
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
     if (sizeof(T) == 4 && h->lay32c.rs > 0) {
         const size_t cb = (size_t)h->lay32c.lds_total_coop * sizeof(float);
@@ -1219,8 +1254,6 @@ int set_lds_limit(nmpc_handle_s* h)
     } else if (spec_bytes > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve_spec<T>(h->lps, L.glb, L.rs)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)spec_bytes));
-        if (auto f = pick_solve_spec<T>(h->lps, L.glb, L.rs, true))
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)spec_bytes));
     }
     return 0;
 }
@@ -1383,7 +1416,9 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
         if (hipGetDeviceProperties(&prop, cfg->device_id) == hipSuccess)
             h->n_simd = prop.multiProcessorCount * 4; // 4 SIMDs per CU
     }
-    int rc = set_lds_limit<float>(h);
+    int rc = h->dflag.reserve(4 * sizeof(int));
+    if (rc == 0 && hipMemset(h->dflag.p, 0, 4 * sizeof(int)) != hipSuccess) rc = fail(NMPC_ERR_HIP, "hipMemset failed");
+    if (rc == 0) rc = set_lds_limit<float>(h);
     if (rc == 0) rc = set_lds_limit<double>(h);
     if (rc) {
         nmpc_destroy(h);
@@ -1514,6 +1549,11 @@ int nmpc_hypotheses_to_ellipses_f64(nmpc_handle h, const double* hypos, int32_t 
 {
     return hypotheses_to_ellipses<double>(h, hypos, P, cur, H, human_size, eps, enlarge, extra_margin, B, dyn, n_obs);
 }
+
+int nmpc_loop_pre_f32(nmpc_handle h, const nmpc_loop_args* a) { return loop_step<float>(h, a, false); }
+int nmpc_loop_pre_f64(nmpc_handle h, const nmpc_loop_args* a) { return loop_step<double>(h, a, false); }
+int nmpc_loop_post_f32(nmpc_handle h, const nmpc_loop_args* a) { return loop_step<float>(h, a, true); }
+int nmpc_loop_post_f64(nmpc_handle h, const nmpc_loop_args* a) { return loop_step<double>(h, a, true); }
 
 int nmpc_last_kernel_ms(nmpc_handle h, float* ms)
 {

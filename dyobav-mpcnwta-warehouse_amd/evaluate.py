@@ -14,7 +14,9 @@ Semantics of the reference's evaluation loop for the MPC tracker with the consta
 
 One time step = CV prediction -> obstacle rows -> reference windows -> ``nmpc_assemble_params`` (f1) ->
 ``nmpc_solve_batch`` -> first action -> agent motion -> metrics, for all scenarios at once; nothing leaves HBM
-between steps. Where the reference runs ``max_num_run`` scenarios one after another (main_base.py:448-464), this
+between steps. Everything around the solve is two HIP kernels (``nmpc_loop_pre_*`` / ``nmpc_loop_post_*``,
+``csrc/nmpc_step.h``); the torch expressions further down (``fused=False``) are the same arithmetic written out op by
+op -- they were the implementation of rounds 1-2 and stay as the independent check of the kernels. Where the reference runs ``max_num_run`` scenarios one after another (main_base.py:448-464), this
 runs them side by side. Pedestrian stagger uses a seeded torch generator (the reference's ``random`` is unseeded).
 """
 from __future__ import annotations
@@ -90,9 +92,11 @@ class BatchEvaluator:
                  human_starts: np.ndarray, human_paths: np.ndarray, map_polygons: np.ndarray, dtype=np.float64,
                  human_stagger: float = 0.0, seed: int = 0, mode: str = "work",
                  tuning: Optional[Sequence[float]] = None, lin_vel_max: float = 1.5, warm_start: bool = False,
-                 compact: Optional[bool] = None):
+                 compact: Optional[bool] = None, fused: bool = True):
         import torch
         self.torch = torch
+        self.fused = fused
+        self.time_solves = True     # record the HIP-event time of every batched solve (one event wait per time step)
         self.cfg = config
         self.dt = np.dtype(dtype)
         self.tdt = torch.float32 if self.dt == np.float32 else torch.float64
@@ -256,6 +260,124 @@ class BatchEvaluator:
         """``record``: if a list, one dict per time step is appended with host copies of what the step saw and
         produced (robot, humans, P, y_in, U) -- for step-by-step checks against the sequential API; costs a
         device->host copy per step."""
+        return self._run_fused(max_steps, record) if self.fused else self._run_torch(max_steps, record)
+
+    def _run_fused(self, max_steps, record):
+        """The time step as two HIP kernels around f1 + solve (csrc/nmpc_step.h)."""
+        torch = self.torch
+        B, N, H = self.B, self.N, self.H
+        dev, tdt = self.dev, self.tdt
+        z = lambda *shape, dtype=tdt, fill=0.0: torch.full(shape, fill, dtype=dtype, device=dev)
+        alive = z(B, dtype=torch.uint8, fill=1)
+        collision, complete = z(B, dtype=torch.uint8, fill=0), z(B, dtype=torch.uint8, fill=0)
+        steps = z(B, dtype=torch.long, fill=0)
+        last_u = z(B, 2)
+        traj = torch.empty(B, max_steps + 1, 3, dtype=tdt, device=dev)
+        traj[:, 0] = self.robot
+        acts = z(B, max(max_steps, 1), 2, fill=float("nan"))
+        clr_dyn = z(B, fill=float("inf"))
+        clr_stc = self._polygon_distance(self.robot[:, :2]).contiguous()
+        d0 = torch.cdist(self.robot[:, None, :2], self.ref_traj[:, :, :2])[:, 0]
+        dev_sum = d0.min(dim=1).values.clone()      # trajectory metrics include the start state (robot.past_traj[0])
+        dev_max = dev_sum.clone()
+        n_traj = z(B, fill=1.0)
+        state_c, last_u_c, refs_c, speed_c = z(B, 3), z(B, 2), z(B, N, 3), z(B)
+        dyn_c = z(B, H, N + 1, 6)
+        ya_buf = z(B, 2 * N)
+        self.hidx = self.hidx.contiguous()
+        self.hcount = self.hcount.contiguous()
+        self.idx_ref = self.idx_ref.contiguous()
+        self.hist = self.hist.contiguous()
+        self.humans = self.humans.contiguous()
+        self.robot = self.robot.contiguous()
+        ref_len = self.ref_len.to(torch.long).contiguous()
+        a = _capi.NmpcLoopArgs()
+        a.B, a.H, a.W, a.Lmax, a.M, a.max_steps = B, H, int(self.hpath.shape[2]), int(self.ref_traj.shape[1]), int(self.polys.shape[0]), max(max_steps, 1)
+        a.base_speed, a.lin_vel_max, a.human_size, a.human_vmax = self.base_speed, self.lin_vel_max, HUMAN_SIZE, HUMAN_VMAX
+        for name, t in (("robot", self.robot), ("last_u", last_u), ("humans", self.humans), ("hist", self.hist), ("hcount", self.hcount),
+                        ("hidx", self.hidx), ("hpath", self.hpath), ("ref_traj", self.ref_traj), ("ref_len", ref_len),
+                        ("idx_ref", self.idx_ref), ("goal", self.goal), ("polys", self.polys), ("alive", alive),
+                        ("collision", collision), ("complete", complete), ("steps", steps), ("clr_dyn", clr_dyn),
+                        ("clr_stc", clr_stc), ("dev_sum", dev_sum), ("dev_max", dev_max), ("n_traj", n_traj), ("traj", traj),
+                        ("acts", acts), ("state_c", state_c), ("last_u_c", last_u_c), ("refs_c", refs_c), ("speed_c", speed_c),
+                        ("dyn_c", dyn_c), ("U", self.U), ("y", self.y)):
+            assert t.is_contiguous(), name
+            setattr(a, name, t.data_ptr())
+        solve_ms = []
+        n_steps_run = 0
+        for kt in range(max_steps):
+            if not bool(alive.any()):
+                break
+            n_steps_run = kt + 1
+            idx = torch.nonzero(alive, as_tuple=False).squeeze(1).contiguous() if self.compact else None
+            nA = int(idx.numel()) if idx is not None else B
+            full = nA == B
+            Pa = self.P if full else self.P[:nA]
+            Ua = self.U if full else self._Ua[:nA]
+            ya = self.y if full else ya_buf[:nA]
+            st = None
+            if self.stagger_replay is not None:
+                st = self.stagger_replay.pop(0).to(tdt).contiguous()
+            elif self.stagger > 0:
+                sign = torch.randint(0, 2, (B, H), generator=self.gen, device=dev) * 2 - 1
+                mag = torch.randint(0, 11, (B, H), generator=self.gen, device=dev).to(tdt) / 10
+                st = (sign.to(tdt) * mag * self.stagger).contiguous()
+            a.n_run, a.step = nA, kt
+            a.run = None if full else idx.data_ptr()
+            a.stagger = None if st is None else st.data_ptr()
+            a.U_c, a.y_c, a.gather_y = Ua.data_ptr(), ya.data_ptr(), int(not full)
+            self.h.loop_step(self.dt, a, post=False)
+            self.h.assemble_params(self.dt, nA, Pa, last_u_c, state_c, refs_c, speed_c, self.tuning, self.stcw, self.dynw,
+                                   self.polys, dyn_c[:nA])
+            if record is not None:
+                rec = dict(robot=self.robot.cpu().numpy(), humans=self.humans.cpu().numpy(), alive=alive.bool().cpu().numpy(),
+                           y_in=self.y.cpu().numpy())
+            u0 = None
+            if self.warm_start and kt > 0:
+                shifted = torch.cat([self.U[:, 2:], self.U[:, -2:]], dim=1)
+                u0 = shifted.contiguous() if full else shifted.index_select(0, idx).contiguous()
+            hs = self.h
+            if self._h_by_waves:      # latency-kernel family: W by the size of the running batch (results unchanged)
+                cap = 3 * self._n_simd if self.dt == np.float32 else 2 * self._n_simd     # resident wavefronts
+                hs = self._h_by_waves[min(4, max(2, cap // max(nA, 1)))]
+            if self.dispatch_by_history and nA >= self.dispatch_min_batch:
+                if kt > 0:
+                    prev = self._evals if full else self._evals.index_select(0, idx)
+                    hs.set_dispatch_order(torch.argsort(prev, descending=True, stable=True).to(torch.int32))
+                info = self._info[:nA]
+            else:
+                info = None
+            hs.solve_raw(self.dt, Pa, nA, Ua, u0=u0, y=ya, y_is_input=kt > 0, info=info, sync=False)
+            if info is not None:
+                if full:
+                    self._evals.copy_(info[:, 4])
+                else:
+                    self._evals.index_copy_(0, idx, info[:, 4].contiguous())
+            self.h.loop_step(self.dt, a, post=True)
+            if record is not None:
+                Pfull = self.P if full else torch.zeros_like(self.P).index_copy_(0, idx, Pa)
+                rec.update(P=Pfull.cpu().numpy(), U=self.U.cpu().numpy())
+                record.append(rec)
+            if self.time_solves:
+                solve_ms.append(hs.last_kernel_ms())
+        alive_b, collision_b, complete_b = alive.bool(), collision.bool(), complete.bool()
+        collision_b = collision_b | alive_b                                      # time-out, main_base.py:407-410
+        T_run = n_steps_run
+        A = acts[:, :T_run]
+        # rows after a scenario's end repeat its last state
+        trj = traj[:, :T_run + 1]
+        last = steps.clamp(max=T_run)
+        t_idx = torch.minimum(torch.arange(T_run + 1, device=dev)[None, :], last[:, None])
+        trj = torch.gather(trj, 1, t_idx[..., None].expand(-1, -1, 3))
+        smooth = action_smoothness(A)
+        return EvaluationResult(
+            collision=collision_b.cpu().numpy(), complete=complete_b.cpu().numpy(), steps=steps.cpu().numpy(),
+            smoothness=smooth.cpu().numpy(), clearance=clr_stc.cpu().numpy(), clearance_dyn=clr_dyn.cpu().numpy(),
+            deviation=torch.stack([dev_sum / n_traj, dev_max], dim=1).cpu().numpy(),
+            trajectory=trj.cpu().numpy(), actions=A.cpu().numpy(), solve_ms=solve_ms)
+
+    def _run_torch(self, max_steps: int = 120, record: Optional[list] = None) -> EvaluationResult:
+        """The same time step written out as torch expressions (rounds 1-2): the independent check of the kernels."""
         torch = self.torch
         B, N, ts = self.B, self.N, self.ts
         alive = torch.ones(B, dtype=torch.bool, device=self.dev)

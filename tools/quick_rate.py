@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: solves/s of one BASELINE workload from the kernel time alone (no CPU baseline, no accuracy section).
-   usage: quick_rate.py [cfg1|cfg2|cfg4] [B] [launches]   env: LW (latency_waves), COOP (coop_waves), RT (reg_table), DT=f64"""
+   usage: quick_rate.py [cfg1|cfg2|cfg4] [B] [launches]   env: LW (latency_waves), COOP (coop_waves), RT (reg_table), DT=f64,
+   AX (axis_aligned), STAGED (staged), POLISH=1, FAMILY, ORDER=lpt"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,6 +19,7 @@ cfg = nm.default_config_struct()
 cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs = L.N, L.Nother, L.Nstc, L.Ndyn
 cfg.max_active_dynobs = spec["n_ped"] * spec["n_hyp"]
 cfg.latency_waves = int(os.environ.get("LW", "0")); cfg.coop_waves = int(os.environ.get("COOP", "0")); cfg.reg_table = int(os.environ.get("RT", "0"))
+cfg.axis_aligned = int(os.environ.get("AX", "0")); cfg.staged = int(os.environ.get("STAGED", "0")); cfg.polish = int(os.environ.get("POLISH", "0"))
 h = nm.Handle(cfg)
 P = np.ascontiguousarray(P, dtype=dt)
 U = np.empty((B, 2 * L.N), dt); it = np.empty((B, 2), np.int32); st = np.empty(B, np.int32)
@@ -33,4 +35,5 @@ if os.environ.get("ORDER") == "lpt":   # longest first, by the evaluation counts
         h.solve_raw(dt, P, B, U, status=st, iters=it)
         ms.append(h.last_kernel_ms())
 k = float(np.mean(ms[1:]))
+print(f"{h.last_launch_info()} ", end="")
 print(f"{wl} B={B} {dt.__name__}: kernel {k:.1f} ms -> {B / k * 1e3:.0f} solves/s; inner iters mean {it[:, 1].mean():.0f}; converged {np.mean(st == 0):.4f}; U checksum {float(np.abs(U).sum()):.6f}")
