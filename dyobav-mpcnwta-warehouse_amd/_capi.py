@@ -45,7 +45,7 @@ class NmpcConfigStruct(C.Structure):
         ("max_solver_time_us", C.c_double),
         ("coop_waves", C.c_int32), ("axis_aligned", C.c_int32), ("reg_table", C.c_int32), ("staged", C.c_int32),
         ("polish", C.c_int32), ("polish_max_outer_iterations", C.c_int32), ("polish_max_inner_iterations", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("staged_evals", C.c_int32),
         ("polish_tolerance", C.c_double), ("polish_delta_tolerance", C.c_double),
     ]
 

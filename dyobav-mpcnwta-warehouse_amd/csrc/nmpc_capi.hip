@@ -334,29 +334,38 @@ __global__ __launch_bounds__(256) void axis_scan_kernel(const T* P, int np, int 
     if (skew) *flag = epoch; // (this call's epoch: the flag needs no reset between calls)
 }
 
-// Resumable solve, ranking of the second launch: bucket = the top 10 bits of ||F2|| (as float; monotonic for values
-// >= 0) the pilot left in the parked state; finished instances go to bucket 0. Counting sort, descending.
+// Resumable solve, ranking of the next launch: counting sort, descending, of a key the parked state holds -- key 0: the
+// hard-constraint violation ||F2|| (bucket = the top 10 bits of the float: monotonic for values >= 0), key 1: the psi
+// evaluations used so far (64 per bucket). Finished instances go to bucket 0.
 constexpr int kRankBuckets = 1024;
 template <typename T>
-__device__ __forceinline__ int rank_bucket(const T* resume, const int* status, int b)
+__device__ __forceinline__ int rank_bucket(const T* resume, const int* status, int b, int key)
 {
     if (status[b] != -1) return 0;
-    const float f = (float)resume[(size_t)b * nmpc::kResumeStride + 6 * 64 + 3];
-    const unsigned bits = __float_as_uint(f >= 0.0f ? f : 0.0f) >> 21;
+    const T* sc = resume + (size_t)b * nmpc::kResumeStride + 6 * 64;
+    unsigned bits;
+    if (key == 0) {
+        const float f = (float)sc[3];
+        bits = __float_as_uint(f >= 0.0f ? f : 0.0f) >> 21;
+    } else {
+        bits = (unsigned)((int)sc[7]) >> 6;
+    }
     return (int)(bits < (unsigned)kRankBuckets ? bits : kRankBuckets - 1);
 }
 template <typename T>
-__global__ __launch_bounds__(256) void rank_hist_kernel(const T* resume, const int* status, int B, int* hist)
+__global__ __launch_bounds__(256) void rank_hist_kernel(const T* resume, const int* status, int B, int* hist, int key)
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b < B) atomicAdd(&hist[rank_bucket(resume, status, b)], 1);
+    if (b < B) atomicAdd(&hist[rank_bucket(resume, status, b, key)], 1);
 }
 // offs[q] = number of instances in buckets above q (one workgroup of kRankBuckets threads; reversed inclusive scan)
-__global__ __launch_bounds__(kRankBuckets) void rank_scan_kernel(const int* hist, int* offs)
+// (the counters are left zeroed for the next ranking: no memset between launches)
+__global__ __launch_bounds__(kRankBuckets) void rank_scan_kernel(int* hist, int* offs)
 {
     __shared__ int sh[kRankBuckets];
     const int t = threadIdx.x;                 // t = 0 is the top bucket
     const int mine = hist[kRankBuckets - 1 - t];
+    hist[kRankBuckets - 1 - t] = 0;
     sh[t] = mine;
     __syncthreads();
     for (int d = 1; d < kRankBuckets; d <<= 1) {
@@ -368,10 +377,10 @@ __global__ __launch_bounds__(kRankBuckets) void rank_scan_kernel(const int* hist
     offs[kRankBuckets - 1 - t] = sh[t] - mine;
 }
 template <typename T>
-__global__ __launch_bounds__(256) void rank_scatter_kernel(const T* resume, const int* status, int B, int* offs, int* order)
+__global__ __launch_bounds__(256) void rank_scatter_kernel(const T* resume, const int* status, int B, int* offs, int* order, int key)
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b < B) order[atomicAdd(&offs[rank_bucket(resume, status, b)], 1)] = b;
+    if (b < B) order[atomicAdd(&offs[rank_bucket(resume, status, b, key)], 1)] = b;
 }
 
 // Polish: fp64 copies of the selected instances' parameters and of the main solve's (u, y, c) / results back into the
@@ -762,7 +771,7 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
     }
     pl.threads = waves ? 64 * waves : 64;
     pl.mode = coop > 1 ? 2 : waves ? 1 : 0;
-    pl.stageable = pl.mode == 0 && h->cfg.max_solver_time_us <= 0;
+    pl.stageable = pl.mode != 2 && h->cfg.max_solver_time_us <= 0; // (one-wavefront and latency kernels park / resume)
     return pl;
 }
 
@@ -818,38 +827,55 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
     if (int rc = prepare_axis<T>(h, pl.has_axis, k, B)) return rc;
     h->last_mode = pl.mode;
     h->last_axis = pl.has_axis ? k.axis_mode : -1;
-    // resumable solve: automatic for batches that fill the device at least four times over with the one-wavefront kernel
-    int staged = h->cfg.staged;
-    if (staged == 0) {
-        const int wpe_tp = sizeof(T) == 8 ? NMPC_WPE_F64 : L.rs >= kRegSlotsLarge ? 2 : L.rs > 0 ? 3 : NMPC_WPE_F32;
-        const int resident = std::max(1, std::min<int>(wpe_tp * h->n_simd,
-                                                       (int)(kLdsLimit / ((size_t)L.lds_total * sizeof(T))) * (h->n_simd / 4)));
-        staged = B >= 4 * resident ? 1 : -1;
-    }
-    if (staged < 0 || !allow_staging || !pl.stageable || k.order || !k.status || staged >= h->cfg.max_outer_iterations) staged = 0;
-    h->last_staged = staged;
-    if (staged == 0) return launch_plan<T>(h, pl, k, B);
+    // Resumable solve: up to two stage boundaries (outer-iteration count, ranking key of the launch that follows).
+    //  * first (nmpc_config.staged, ranked by ||F2||) -- the instances whose hard constraints are still violated after the
+    //    first inner solve are the ones that will run into the iteration caps. Automatic (one outer iteration) for
+    //    batches that fill the device at least four times over with the one-wavefront kernel: started first, the long
+    //    solves no longer end the launch alone (configs[2] `passing`: 156 -> 121 ms); and for the latency kernel with
+    //    about one workgroup per SIMD, where every workgroup is resident at once and the order decides which long solves
+    //    share a SIMD to the end (configs[1]: 32.6 -> 28.5 ms; costs ~1.5 ms where most instances converge early).
+    //  * second (nmpc_config.staged_evals, ranked by the evaluations used so far) -- explicit only: every boundary is a
+    //    barrier (each stage ends with ITS longest instance), and late boundaries lost more to that than the better
+    //    ranking returned in every measurement (tools/exp_cfg1_order2.py, tools/sim_stages.py).
+    int caps[2] = {h->cfg.staged, h->cfg.staged_evals};
+    const int wpe_tp = sizeof(T) == 8 ? NMPC_WPE_F64 : L.rs >= kRegSlotsLarge ? 2 : L.rs > 0 ? 3 : NMPC_WPE_F32;
+    const int resident = std::max(1, std::min<int>(wpe_tp * h->n_simd,
+                                                   (int)(kLdsLimit / ((size_t)L.lds_total * sizeof(T))) * (h->n_simd / 4)));
+    const int lat_cap = sizeof(T) == 4 ? h->n_simd : h->n_simd / 2;
+    if (caps[0] == 0) caps[0] = ((pl.mode == 0 && B >= 4 * resident) || (pl.mode == 1 && B > lat_cap / 2 && B <= lat_cap)) ? 1 : -1;
+    if (caps[1] == 0) caps[1] = -1;
+    const bool stageable = allow_staging && pl.stageable && !k.order && k.status;
+    int n_stage = 0, stage_cap[2], stage_key[2];
+    for (int i = 0; i < 2; ++i)
+        if (stageable && caps[i] > 0 && caps[i] < h->cfg.max_outer_iterations && (n_stage == 0 || caps[i] > stage_cap[n_stage - 1])) {
+            stage_cap[n_stage] = caps[i];
+            stage_key[n_stage] = i;
+            ++n_stage;
+        }
+    h->last_staged = n_stage == 0 ? 0 : n_stage == 1 ? stage_cap[0] : 100 * stage_cap[0] + stage_cap[1];
+    if (n_stage == 0) return launch_plan<T>(h, pl, k, B);
 
     if (int rc = h->dresume.reserve((size_t)B * nmpc::kResumeStride * sizeof(T))) return rc;
     if (int rc = h->dorder2.reserve((size_t)B * sizeof(int))) return rc;
-    if (int rc = h->dhist.reserve(2 * kRankBuckets * sizeof(int))) return rc;
     k.resume = static_cast<T*>(h->dresume.p);
-    nmpc::KParams<T> k1 = k;
-    k1.stage_outer_cap = staged;
-    if (int rc = launch_plan<T>(h, pl, k1, B)) return rc;
     int* hist = static_cast<int*>(h->dhist.p);
     int* offs = hist + kRankBuckets;
     int* order2 = static_cast<int*>(h->dorder2.p);
-    HIP_TRY(hipMemsetAsync(hist, 0, kRankBuckets * sizeof(int), h->stream));
     const int nb = (B + 255) / 256;
-    hipLaunchKernelGGL(rank_hist_kernel<T>, dim3(nb), dim3(256), 0, h->stream, k.resume, k.status, B, hist);
-    hipLaunchKernelGGL(rank_scan_kernel, dim3(1), dim3(kRankBuckets), 0, h->stream, hist, offs);
-    hipLaunchKernelGGL(rank_scatter_kernel<T>, dim3(nb), dim3(256), 0, h->stream, k.resume, k.status, B, offs, order2);
-    HIP_TRY(hipGetLastError());
-    nmpc::KParams<T> k2 = k;
-    k2.stage_in = 1;
-    k2.order = order2;
-    return launch_plan<T>(h, pl, k2, B);
+    for (int i = 0; i <= n_stage; ++i) {
+        nmpc::KParams<T> ki = k;
+        ki.stage_in = i > 0;
+        ki.stage_outer_cap = i < n_stage ? stage_cap[i] : 0;
+        if (i > 0) ki.order = order2;
+        if (int rc = launch_plan<T>(h, pl, ki, B)) return rc;
+        if (i == n_stage) break;
+        hipLaunchKernelGGL(rank_hist_kernel<T>, dim3(nb), dim3(256), 0, h->stream, k.resume, k.status, B, hist, stage_key[i]);
+        hipLaunchKernelGGL(rank_scan_kernel, dim3(1), dim3(kRankBuckets), 0, h->stream, hist, offs);
+        hipLaunchKernelGGL(rank_scatter_kernel<T>, dim3(nb), dim3(256), 0, h->stream, k.resume, k.status, B, offs, order2,
+                           stage_key[i]);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
 }
 
 template <typename T>
@@ -1313,7 +1339,7 @@ int nmpc_default_config(nmpc_config* c)
     c->polish = 0;
     c->polish_max_outer_iterations = 4;
     c->polish_max_inner_iterations = 300;
-    c->reserved0 = 0;
+    c->staged_evals = 0;
     c->polish_tolerance = 1e-6;
     c->polish_delta_tolerance = 1e-5;
     return 0;
@@ -1369,7 +1395,7 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "akkt_form = %d (0 = OpEn source form, 1 = documented form)", cfg->akkt_form);
     if (!(cfg->max_solver_time_us >= 0))
         return fail(NMPC_ERR_INVALID_ARGUMENT, "max_solver_time_us < 0");
-    if (cfg->reserved0 != 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "reserved fields must be 0");
+    if (cfg->staged_evals < -1) return fail(NMPC_ERR_INVALID_ARGUMENT, "staged_evals = %d < -1", cfg->staged_evals);
     if (cfg->axis_aligned < -1 || cfg->axis_aligned > 1)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "axis_aligned = %d (0 automatic, 1 promised, -1 never)", cfg->axis_aligned);
     if (cfg->staged < -1) return fail(NMPC_ERR_INVALID_ARGUMENT, "staged = %d < -1", cfg->staged);
@@ -1418,6 +1444,8 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
     }
     int rc = h->dflag.reserve(4 * sizeof(int));
     if (rc == 0 && hipMemset(h->dflag.p, 0, 4 * sizeof(int)) != hipSuccess) rc = fail(NMPC_ERR_HIP, "hipMemset failed");
+    if (rc == 0) rc = h->dhist.reserve(2 * kRankBuckets * sizeof(int)); // (bucket counters of the resumable solve, kept zeroed)
+    if (rc == 0 && hipMemset(h->dhist.p, 0, 2 * kRankBuckets * sizeof(int)) != hipSuccess) rc = fail(NMPC_ERR_HIP, "hipMemset failed");
     if (rc == 0) rc = set_lds_limit<float>(h);
     if (rc == 0) rc = set_lds_limit<double>(h);
     if (rc) {

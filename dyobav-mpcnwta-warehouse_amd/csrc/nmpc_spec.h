@@ -78,6 +78,8 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         c = kc->c0v ? kc->c0v[inst] : kc->c_init;
     }
     if (!I.act) uv = uw = yv = yw = 0;
+    const int resuming = __builtin_amdgcn_readfirstlane(cold_args<T>()->stage_in);
+    if (resuming && cold_args<T>()->status[inst] != -1) return; // finished in an earlier launch (uniform)
 
     // PANOC cache (same names as solve_instance)
     T gv = 0, gw = 0, gpv = 0, gpw = 0, hv = 0, hw = 0, sv = 0, sw = 0, dv = 0, dw = 0, fv = 0, fw = 0, pv = 0, pw = 0;
@@ -161,6 +163,26 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         uv = q4.a, uw = q4.b, gv = q4.c, gw = q4.d;
     };
 
+    if (resuming) {
+        // resumable solve (KParams::resume): the state the instance parked behind the ALM update of its last outer
+        // iteration; every wavefront of the workgroup loads the same values
+        const T* rs = cold_args<T>()->resume + (size_t)inst * kResumeStride;
+        uv = rs[0 * 64 + I.lane], uw = rs[1 * 64 + I.lane], yv = rs[2 * 64 + I.lane], yw = rs[3 * 64 + I.lane];
+        gpv = rs[4 * 64 + I.lane], gpw = rs[5 * 64 + I.lane];
+        const T* sc = rs + 6 * 64;
+        c = sc[0];
+        akkt_tol = sc[1];
+        dyn = sc[2];
+        f2n = sc[3];
+        alm_iter = (int)sc[4];
+        outer = (int)sc[5] + 1;
+        inner_total = (int)sc[6];
+        alg_psi = (int)sc[7];
+        alg_grad = (int)sc[8];
+        rounds = (int)sc[9];
+        yv = tclamp(yv, T(-1e12), T(1e12));
+        yw = tclamp(yw, T(-1e12), T(1e12));
+    }
     int phase = SP_INIT_A;
     T ev = uv, ew = uw, ec = c;
     T inv_cdiv = T(1) / (c > T(1) ? c : T(1));
@@ -455,6 +477,33 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                     }
                 }
                 return;
+            }
+            {
+                const int cap = kc->stage_outer_cap;
+                if (cap > 0 && outer >= cap) { // park the instance here (KParams::resume); wavefront 0 writes
+                    if (wv == 0) {
+                        int ri = inst;
+                        asm volatile("" : "+s"(ri));
+                        T* rs = kc->resume + (size_t)ri * kResumeStride;
+                        rs[0 * 64 + I.lane] = uv, rs[1 * 64 + I.lane] = uw, rs[2 * 64 + I.lane] = yv, rs[3 * 64 + I.lane] = yw;
+                        rs[4 * 64 + I.lane] = gpv, rs[5 * 64 + I.lane] = gpw;
+                        if (I.lane == 0) {
+                            T* sc = rs + 6 * 64;
+                            sc[0] = c;
+                            sc[1] = akkt_tol;
+                            sc[2] = dyn;
+                            sc[3] = f2n;
+                            sc[4] = T(alm_iter);
+                            sc[5] = T(outer);
+                            sc[6] = T(inner_total);
+                            sc[7] = T(alg_psi);
+                            sc[8] = T(alg_grad);
+                            sc[9] = T(rounds);
+                            kc->status[ri] = -1;
+                        }
+                    }
+                    return;
+                }
             }
             request_uniform(uv, uw, c, true);
             phase = SP_INIT_A;

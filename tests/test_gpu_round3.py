@@ -113,6 +113,27 @@ def test_staged_solve_is_bit_identical_to_the_one_launch_solve(dtype, ov):
             assert np.array_equal(r[k], base[k]), (staged, k)
 
 
+@pytest.mark.parametrize("waves,axis", [(3, 0), (2, -1), (4, 0)])
+def test_staged_latency_kernel_is_bit_identical_too(waves, axis):
+    """The latency (speculative) kernel parks and resumes the same way; one or two stage boundaries, either ranking key."""
+    lay = ParamLayout(N=20, Ndyn=15)
+    B = 384
+    P = nm.scenarios.make_batch(B, lay, seed=8, n_ped=2, n_hyp=5).astype(np.float32)
+    base = None
+    for staged, staged_evals in ((-1, -1), (-1, 7), (1, -1), (2, 6), (0, 0)):
+        with nm.Handle(_cfg(lay, 10, staged=staged, staged_evals=staged_evals, latency_waves=waves, axis_aligned=axis)) as h:
+            r = h.solve(P)
+            li = h.last_launch_info()
+        assert li["family"] == "latency"
+        assert li["staged_outer_iterations"] == {(-1, -1): 0, (-1, 7): 7, (1, -1): 1, (2, 6): 206, (0, 0): 0}[(staged, staged_evals)]
+        if base is None:
+            base = r
+            assert (r["iters"][:, 0] > 7).sum() > B // 2
+            continue
+        for k in ("U", "cost", "status", "iters", "y", "info"):
+            assert np.array_equal(r[k], base[k]), (staged, staged_evals, k)
+
+
 def test_staged_solve_other_dimensions_and_automatic_choice():
     # N = 40 (one lane per step, obstacle table in the global workspace), N = 30 (two lanes per step)
     for N, Ndyn, B in ((40, 160, 48), (30, 12, 96)):
