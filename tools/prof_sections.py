@@ -15,6 +15,8 @@ spec = nm.scenarios.BENCH_CONFIGS[key]
 cfg = nm.default_config_struct(); cfg.lbfgs_memory = int(os.environ.get("LBFGS_MEM", "10")); cfg.latency_waves = int(os.environ.get("LW", "1"))
 cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs = L.N, L.Nother, L.Nstc, L.Ndyn
 cfg.max_active_dynobs = spec["n_ped"] * spec["n_hyp"]
+cfg.staged = -1                                   # (the parked state does not carry the profile counters)
+cfg.axis_aligned = int(os.environ.get("AX", "0"))
 h = nm.Handle(cfg)
 P = P.astype(np.float32)
 U = np.empty((B, 2 * L.N), np.float32); info = np.empty((B, 24), np.float32)
