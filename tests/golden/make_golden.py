@@ -479,6 +479,34 @@ def hypotheses_fixture(K=8, seed=123):
 
 
 # ---------------------------------------------------------------------------------------------------------
+def scenario0_static_map(g, ct):
+    """BASELINE configs[0]'s static obstacles: the reference's own map pipeline (main_base.py:123-127) on its own PGM.
+    The reference classes are imported as they are; the two third-party functions they call and this image lacks
+    (skimage.measure.find_contours, pyclipper's mitre offset) come from _map_standins.py. Returns the inflated obstacle
+    polygons and the deflated boundary in world coordinates, and the raw bounding rectangles in sim (pixel) coordinates."""
+    import importlib
+    import _map_standins
+    _map_standins.install()
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "basic_map" or k.startswith("basic_map.")
+             or k == "interfaces.map_interface"}
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            mi_mod = importlib.import_module("interfaces.map_interface")
+            mi = mi_mod.MapInterface(g["map_dir"])
+            occ = mi.get_occ_map_from_pgm(g["map_file"], 120, inversed_pixel=True)
+            geo = mi.cvt_occ2geo(occ, inflate_margin=0.5 + 0.2)      # vehicle_width + vehicle_margin (mpc_*.yaml)
+        raw = [[[float(v[0]), float(v[1])] for v in poly] for poly in geo.obstacle_list]
+        geo.coords_cvt(ct)
+        world = [[[float(v[0]), float(v[1])] for v in poly] for poly in geo.processed_obstacle_list]
+        boundary = [[float(v[0]), float(v[1])] for v in geo.processed_boundary_coords]
+    finally:
+        for k in [k for k in sys.modules if k == "basic_map" or k.startswith("basic_map.") or k == "interfaces.map_interface"]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    return world, boundary, raw
+
+
 def evaluate_fixture(seed=2024):
     """f3 ("next" row, batched closed-loop evaluator): recordings of the reference pieces the evaluator restates --
       human_walks   basic_agent.Human.run_step (basic_agent.py:52-82) along a node path: states per step and the stagger
@@ -589,6 +617,13 @@ def evaluate_fixture(seed=2024):
     nodes_sim = {k: [float(v[0]), float(v[1])] for k, v in graph["node_dict"].items()}
     nodes_world = {k: [float(x) for x in ct(np.array(v, dtype=float))] for k, v in nodes_sim.items()}
     human_start, robot_start = [160.0, 50.0], [235.0, 100.0, -np.pi / 2]
+    map_world, map_boundary_world, map_raw_sim = scenario0_static_map(g, ct)
+    out["scenario_0_map"] = {
+        "note": "static map of scenario_0: the reference's MapInterface.get_occ_map_from_pgm + cvt_occ2geo "
+                "(OccupancyMap.get_geometric_map -> BlobBounding -> GeometricMap inflated by vehicle_width + vehicle_margin, "
+                "main_base.py:123-127) run on data/warehouse_sim_original/mymap.pgm, converted by coords_cvt(ct2real); "
+                "skimage.measure.find_contours and pyclipper are stand-ins (tests/golden/_map_standins.py)",
+        "inflate_margin": 0.7, "polygons_world": map_world, "boundary_world": map_boundary_world, "polygons_sim_raw": map_raw_sim}
     out["scenario_0"] = {
         "human_starts_sim": [human_start], "human_paths": [[9, 32, 16]], "robot_start_sim": robot_start,
         "robot_path": [16, 32], "nodes_sim": nodes_sim, "nodes_world": nodes_world,

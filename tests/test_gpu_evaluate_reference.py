@@ -140,3 +140,22 @@ def test_config0_scenario_0_one_robot_two_pedestrians(cases):
     assert min_dist > ev.HUMAN_SIZE, min_dist                                                # main_pre.check_collision
     assert np.abs(traj[-1, :2] - goal).max() <= 0.5, traj[-1]
     assert step < 119
+
+
+def test_config0_scenario_0_with_the_warehouse_static_map(cases):
+    """The same closed loop with the warehouse's real static map in it: the 55 inflated rectangles the reference's own
+    map pipeline (MapInterface.cvt_occ2geo, main_base.py:123-127) extracts from data/warehouse_sim_original/mymap.pgm --
+    recorded by tests/golden/make_golden.py with stand-ins for skimage.find_contours / pyclipper -- so that the
+    closest-polygon selection, the half-space rows and the static-obstacle terms see BASELINE configs[0]'s obstacles.
+    Also the reference's timing protocol for this loop (tools/bench_scenario0.py; first 10 samples dropped)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    import bench_scenario0
+    assert len(cases["scenario_0_map"]["polygons_world"]) == 55
+    r = bench_scenario0.run(max_steps=160, with_map=True)
+    print(json.dumps(r))
+    # static obstacles are soft terms of this MPC: dodging the pedestrian who comes down the same 1.7 m corridor the robot
+    # may clip the inflated corner of a shelf; it must not get near the shelf itself (robot radius 0.25 m)
+    assert r["reached_goal"] and r["max_penetration_into_an_inflated_polygon_m"] < 0.15, r
+    assert r["min_pedestrian_distance_m"] > ev.HUMAN_SIZE, r
+    assert r["steps"] < 160 and r["mean_ms"] < 100.0          # (the reference's budget per step: max_solver_time = 0.1 s)
