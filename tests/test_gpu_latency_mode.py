@@ -106,3 +106,29 @@ def test_latency_kernel_agrees_with_throughput_kernel_to_rounding():
     # most instances follow the same path to solver accuracy; a minority is pushed onto another branch of the
     # (non-convex) problem by a last-bit difference early on (DESIGN.md "parity protocol")
     assert np.median(d) < 1e-8 and np.mean(d < 1e-4) >= 0.6
+
+
+def test_latency_kernel_follows_the_throughput_kernel_step_for_step():
+    """The tight half of the comparison above: over the first iterations -- before the solver's own
+    amplification of last-bit differences sets in -- the two compilations must agree to rounding on EVERY instance, with
+    identical iteration and evaluation counts; and at tolerance 1e-8 on the converging family the fixed points coincide."""
+    P = nm.scenarios.make_batch(256, seed=38, ped_mode="oncoming")
+    cfg = nm.default_config_struct()
+    cfg.lip_eps_f64 = cfg.lip_delta_f64 = 1e-4
+    cfg.max_outer_iterations, cfg.max_inner_iterations = 1, 6
+    a, b = _solve(cfg, P, np.float64, 1), _solve(cfg, P, np.float64, 4)
+    assert np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["info"][:, 4:6], b["info"][:, 4:6])
+    d = np.abs(a["U"] - b["U"]).max(axis=1)
+    print("6 inner iterations: median", np.median(d), "q90", np.quantile(d, 0.9), "max", d.max())
+    assert np.quantile(d, 0.9) < 1e-9 and d.max() < 1e-6
+    lay = ParamLayout(N=20, Ndyn=15)
+    P = nm.scenarios.make_batch(192, lay, seed=39, n_ped=2, n_hyp=5, ped_mode="passing")
+    cfg = nm.default_config_struct()
+    cfg.max_active_dynobs = 10
+    cfg.tolerance = cfg.initial_tolerance = cfg.delta_tolerance = 1e-8
+    cfg.max_outer_iterations, cfg.max_inner_iterations = 15, 2000
+    a, b = _solve(cfg, P, np.float64, 1), _solve(cfg, P, np.float64, 4)
+    conv = (a["status"] == 0) & (b["status"] == 0)
+    d = np.abs(a["U"] - b["U"]).max(axis=1)[conv]
+    print("tolerance 1e-8, converged on both:", conv.sum(), "median", np.median(d), "q90", np.quantile(d, 0.9))
+    assert conv.sum() >= 30 and np.median(d) < 1e-7 and np.quantile(d, 0.8) < 1e-4

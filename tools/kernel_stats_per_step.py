@@ -14,5 +14,7 @@ for _, r in t.iterrows():
     if "solve_" in n or "rank_" in n or "axis_scan" in n or "polish_" in n:
         ms = float(r["TotalDurationNs"]) / 1e6
         tot += ms
-        print(f"{n.split('(')[0][-70:]:72s} calls {int(r['Calls']):4d}  total {ms:10.3f} ms  avg {float(r['AverageNs']) / 1e6:10.3f} ms  per step {ms / steps:10.3f} ms")
+        short = n.replace("void ", "").replace("(anonymous namespace)::", "").replace("nmpc::", "")
+        short = short[:short.rfind("(")] if short.endswith(")") else short
+        print(f"{short[-70:]:72s} calls {int(r['Calls']):4d}  total {ms:10.3f} ms  avg {float(r['AverageNs']) / 1e6:10.3f} ms  per step {ms / steps:10.3f} ms")
 print(f"all kernels of a solve call, per step ({steps} steps): {tot / steps:.3f} ms")

@@ -18,7 +18,8 @@ for d in args:
         print(f"== {f}  steps={steps} solve-kernel dispatches={t['Dispatch_Id'].nunique()}")
         per_disp = t.groupby(["Kernel_Name", "Dispatch_Id", "Counter_Name"])["Counter_Value"].sum().reset_index()
         for name, g in per_disp.groupby("Kernel_Name"):
-            short = name.split("(")[0][-60:]
+            short = name.replace("void ", "").replace("(anonymous namespace)::", "")
+            short = short[:short.rfind("(")][-60:]
             row = t[t["Kernel_Name"] == name].iloc[0]
             print(f"   kernel {short}: dispatches={g['Dispatch_Id'].nunique()} grid={row['Grid_Size']} vgpr={row['VGPR_Count']} sgpr={row['SGPR_Count']} scratch={row['Scratch_Size']}")
         tot = per_disp.groupby("Counter_Name")["Counter_Value"].sum() / steps
