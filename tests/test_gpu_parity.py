@@ -272,31 +272,44 @@ def test_config4_long_horizon_obstacle_table_streamed_from_global_memory():
 
 
 def test_fp32_vs_fp64_tolerance_sweep_long_horizon():
-    """BASELINE configs[4]: fp64 vs fp32 at solver tolerances 1e-3 ... 1e-5 (device vs device, reduced batch).
-    Obstacle-free family: both precisions converge to the same controls (median distance shrinks with the tolerance
-    floor of fp32); crowded family (8 x 20 ellipses): only feasibility / finiteness is asserted, the iterates of a
-    non-convex problem stopped by iteration caps are not comparable across precisions."""
+    """BASELINE configs[4]: fp64 vs fp32 at solver tolerances 1e-3 ... 1e-6 (SURVEY.md 8d configuration 5; device vs
+    device, reduced batch). Obstacle-free family: both precisions converge to the same controls, the median distance
+    shrinks with the tolerance down to the floor of fp32 (1e-6 is below it: no further gain, the solves run into the
+    iteration caps instead). The 8 x 20 crowd: on the contract family (pedestrians walking INTO the robot) only
+    feasibility / finiteness can be asserted -- iterates of a non-convex problem stopped by iteration caps are not
+    comparable across precisions; on the `passing` family the instances that converge on both sides are compared."""
     lay = nm.scenarios.ParamLayout(40, 10, 10, 160)
     pr = oracle.Problem(40, 10, 10, 160)
     P_free = nm.scenarios.make_batch(16, lay, seed=6, n_ped=0, n_boxes=0)
     P_crowd = nm.scenarios.make_batch(8, lay, seed=6, n_ped=8, n_hyp=20, ped_mode="oncoming")
     med = {}
-    for tol in (1e-3, 1e-4, 1e-5):
+    P_pass = nm.scenarios.make_batch(12, lay, seed=7, n_ped=8, n_hyp=20, ped_mode="passing")
+    crowd = {}
+    for tol in (1e-3, 1e-4, 1e-5, 1e-6):
         cfg = config_for(pr, tolerance=tol, initial_tolerance=tol)
         with nm.Handle(cfg) as h:
             r64, r32 = h.solve(P_free), h.solve(P_free.astype(np.float32))
             both = (r64["status"] == 0) & (r32["status"] == 0)
             du = np.abs(r64["U"] - r32["U"].astype(np.float64)).max(axis=1)
             med[tol] = float(np.median(du[both])) if both.sum() >= 4 else float(np.median(du))
+            if tol in (1e-3, 1e-4, 1e-5):             # the crowd on the converging family: same comparison, reported
+                p64, p32 = h.solve(P_pass), h.solve(P_pass.astype(np.float32))
+                bp = (p64["status"] == 0) & (p32["status"] == 0)
+                dp = np.abs(p64["U"] - p32["U"].astype(np.float64)).max(axis=1)
+                crowd[tol] = (int(bp.sum()), float(np.median(dp[bp])) if bp.any() else None)
+                assert np.isfinite(p64["U"]).all() and np.isfinite(p32["U"]).all()
             if tol == 1e-4:
                 rc64, rc32 = h.solve(P_crowd), h.solve(P_crowd.astype(np.float32))
                 for r in (rc64, rc32):
                     assert np.isfinite(r["U"]).all() and set(np.unique(r["status"])) <= {0, 1}
                     assert (r["U"][:, 0::2] <= pr.lin_vel_max).all() and (r["U"][:, 0::2] >= pr.lin_vel_min).all()
                     assert (np.abs(r["U"][:, 1::2]) <= pr.ang_vel_max).all()
-    # measured on MI355X: 0.125 / 0.0127 / 0.0018 -- the distance scales with the tolerance (error ~ tol / gamma)
-    assert med[1e-3] < 0.3 and med[1e-4] < 0.04 and med[1e-5] < 0.006, med
+    print("obstacle-free, median |u32 - u64| by tolerance:", med, "; 8 x 20 crowd `passing` (both converged, median):", crowd)
+    # measured on MI355X: 0.125 / 0.0127 / 0.0018 -- the distance scales with the tolerance (error ~ tol / gamma) --
+    # and no better at 1e-6 (fp32's floor)
+    assert med[1e-3] < 0.3 and med[1e-4] < 0.04 and med[1e-5] < 0.006 and med[1e-6] < 0.02, med
     assert med[1e-5] < med[1e-4] < med[1e-3], med
+    assert all(v[1] is None or v[1] < 0.3 for v in crowd.values()), crowd
 
 
 def test_capacity_hint_same_results_and_safe_failure():
