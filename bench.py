@@ -433,6 +433,11 @@ def cpu_baseline(layout, P_host):
     t0 = time.perf_counter()
     oracle.solve_batch(pr, oracle.Options(), Ps[:n1], nthreads=1)
     t_one = time.perf_counter() - t0
+    # the same sample with the reference's own wall-clock cap per solve (max_solver_time = 0.1 s, mpc_builder.py:189)
+    cap_s = 0.1
+    t0 = time.perf_counter()
+    _, rc = oracle.solve_batch(pr, oracle.Options(max_time_s=cap_s), Ps, nthreads=cores)
+    t_cap = time.perf_counter() - t0
     return {"value": sample / t_all, "unit": "solves/s", "cores": cores, "kind": "port",
             "note": "fp64 restatement run to its iteration caps: the reference's own solver would be cut off at its "
                     "max_solver_time (0.1 s per solve, mpc_builder.py:189) -- at %.0f ms per solve on one core most of "
@@ -440,6 +445,10 @@ def cpu_baseline(layout, P_host):
             "sample": f"first {sample} instances of the timed batch, fp64 oracle, OpenMP over instances "
                       f"({t_all:.2f} s wall)",
             "single_core_value": n1 / t_one, "single_core_sample": f"first {n1} instances, 1 thread",
+            "value_with_reference_time_cap": sample / t_cap,
+            "reference_time_cap": {"max_solver_time_s": cap_s, "wall_s": t_cap,
+                                   "out_of_time_frac": float(np.mean(rc["status"] == 2)),
+                                   "converged_frac": float(np.mean(rc["status"] == 0))},
             "converged_frac": float(np.mean(ro["status"] == 0)),
             "open_probe": "unavailable" if not probe["available"] else "build failed", "open_probe_detail": probe}
 

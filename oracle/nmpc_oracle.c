@@ -9,6 +9,14 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+
+static double orc_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 int orc_np(const orc_problem *pr)
 {
@@ -36,6 +44,7 @@ void orc_default_options(orc_options *o)
     o->sy_eps = 1e-10;
     o->akkt_form = 0;
     o->pad_ = 0;
+    o->max_time_s = 0.0;
 }
 
 /* ---------------- double ---------------- */

@@ -66,6 +66,9 @@ typedef struct {
                                     ||gamma*fpr + gamma*(df - df_prev)||, 1 = OpEn documentation ||fpr + df - df_prev||
                                     (= the former / gamma). See DESIGN.md "AKKT residual". */
     int32_t pad_;
+    double max_time_s;           /* wall-clock budget of one solve (the reference: with_max_duration_micros = 0.1 s,
+                                    mpc_builder.py:189): the inner loop stops once it is used up and no further outer
+                                    iteration is started (status 2); 0 = none (default: iteration caps only) */
 } orc_options;
 
 typedef struct {

@@ -624,20 +624,22 @@ static int SUF(panoc_step)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u)
 }
 
 /* OpEn: PANOCOptimizer::solve. Returns inner exit status (0 converged, 1 max iterations). */
-static int SUF(panoc_solve)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u, int max_iter, int *iters, REAL *last_fpr)
+static int SUF(panoc_solve)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u, int max_iter, int *iters, REAL *last_fpr,
+                            double t_end)
 {
     SUF(panoc_init)(cx, pc, u);
-    int num_iter = 0, cont_iters = 1;
+    int num_iter = 0, cont_iters = 1, cont_time = 1;
     int flag = SUF(panoc_step)(cx, pc, u);
-    while (flag && cont_iters) {
+    while (flag && cont_iters && cont_time) {
         num_iter++;
         cont_iters = num_iter < max_iter;
+        if (t_end > 0) cont_time = orc_now() <= t_end;   /* (remaining time checked once per iteration, like OpEn) */
         flag = SUF(panoc_step)(cx, pc, u);
     }
     for (int i = 0; i < cx->n; ++i) u[i] = pc->u_half[i];
     *iters = num_iter;
     *last_fpr = pc->norm_gfpr;
-    return cont_iters ? 0 : 1;
+    return !cont_iters ? 1 : !cont_time ? 2 : 0;
 }
 
 /* OpEn: alm::AlmOptimizer::solve / step */
@@ -659,12 +661,18 @@ int SUF(orc_solve)(const orc_problem *pr, const orc_options *op, const REAL *p, 
     int alm_iter = 0, inner_total = 0, outer = 0, status = 0, converged = 0;
     const REAL SMALL = (REAL)REAL_EPS;
 
+    const double t_end = op->max_time_s > 0 ? orc_now() + op->max_time_s : 0.0;
+    int out_of_time = 0;
     for (int it = 0; it < op->max_outer; ++it) {
+        if (t_end > 0 && it > 0 && orc_now() > t_end) { /* no time left for another outer iteration */
+            out_of_time = 1;
+            break;
+        }
         outer++;
         /* project y on Y = [-1e12, 1e12]^n1 */
         for (int i = 0; i < n1; ++i) y[i] = SUF(rmin)(SUF(rmax)(y[i], (REAL)-1e12), (REAL)1e12);
         int inner_iters;
-        int inner_status = SUF(panoc_solve)(&cx, pc, u, op->max_inner, &inner_iters, &last_fpr);
+        int inner_status = SUF(panoc_solve)(&cx, pc, u, op->max_inner, &inner_iters, &last_fpr, t_end);
         inner_total += inner_iters;
         status = inner_status;
         /* update_lagrange_multipliers: y+ = y + c [F1(u) - Proj_C(F1(u) + y/c)] ; F2 norm */
@@ -703,7 +711,7 @@ int SUF(orc_solve)(const orc_problem *pr, const orc_options *op, const REAL *p, 
         for (int i = 0; i < n1; ++i) y[i] = y_plus[i];
         SUF(pc_reset)(pc);
     }
-    if (!converged) status = 1; /* outer iterations exhausted */
+    if (!converged) status = out_of_time ? 2 : 1; /* out of time / outer iterations exhausted */
     if (res) {
         REAL f;
         SUF(core)(pr, u, 0, 0, p, &f, 0, 0, 0, 0);
