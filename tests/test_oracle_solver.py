@@ -66,3 +66,17 @@ def test_fp32_oracle_tracks_fp64():
     both = (r64["status"] == 0) & (r32["status"] == 0)
     assert both.sum() >= 4
     assert np.median(np.abs(U64 - U32).max(axis=1)[both]) < 2e-2
+
+
+def test_oracle_wall_clock_cap_like_the_reference():
+    """orc_options.max_time_s (the reference builds its solver with_max_duration_micros = 0.1 s, mpc_builder.py:189): a
+    budget that is used up ends the solve NotConvergedOutOfTime; a generous one changes nothing."""
+    import dyobav_mpcnwta_warehouse_amd as nm
+    lay = nm.scenarios.ParamLayout()
+    P = nm.scenarios.make_batch(6, lay, seed=3)
+    pr = oracle.Problem()
+    U0, r0 = oracle.solve_batch(pr, oracle.Options(), P, nthreads=2)
+    U1, r1 = oracle.solve_batch(pr, oracle.Options(max_time_s=1e-4), P, nthreads=2)
+    U2, r2 = oracle.solve_batch(pr, oracle.Options(max_time_s=600.0), P, nthreads=2)
+    assert (r1["status"] == 2).all() and (r1["inner_iters"] < r0["inner_iters"]).all()
+    assert np.array_equal(U0, U2) and np.array_equal(r0["status"], r2["status"])
