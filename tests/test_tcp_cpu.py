@@ -172,3 +172,64 @@ def test_tracker_over_tcp_raises_and_kills_on_error():
 def test_shift_solution():
     U = np.arange(12.0).reshape(2, 6)
     np.testing.assert_array_equal(shift_solution(U), [[2, 3, 4, 5, 4, 5], [8, 9, 10, 11, 10, 11]])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference tree is only in the authoring container")
+def test_the_references_own_tcp_consumer_accepts_our_answers():
+    """What CAN be pinned of row f4 without opengen: the consumer side. The REFERENCE's TrajectoryTracker.run_solver_tcp
+    (pkg_mpc_tracker/trajectory_tracker.py:385-416, imported from /root/reference with stub `opengen` / `casadi` modules
+    for its import lines) is run against this repo's OptimizerTcpManager + server -- `.call(parameters)`, `.is_ok()`,
+    `.get().solution / .cost / .exit_status / .solve_time_ms`, and on an error `.get().code / .message` + `.kill()` --
+    and must return exactly what its in-process twin run_solver returns for the same solver answers."""
+    import importlib
+    import sys
+    saved = {k: sys.modules.get(k) for k in ("opengen", "opengen.opengen", "opengen.opengen.tcp", "opengen.opengen.tcp.solver_status",
+                                             "casadi", "casadi.casadi", "configs", "pkg_mpc_tracker", "pkg_mpc_tracker.trajectory_tracker")}
+    og = types.ModuleType("opengen")
+    og.__path__ = []
+    sub = types.ModuleType("opengen.opengen")
+    sub.__path__ = []
+    tcpm = types.ModuleType("opengen.opengen.tcp")
+    tcpm.__path__ = []
+    ss = types.ModuleType("opengen.opengen.tcp.solver_status")
+    ss.SolverStatus = object
+    og.opengen, sub.tcp, tcpm.solver_status = sub, tcpm, ss
+    og.tcp = types.SimpleNamespace(OptimizerTcpManager=tcp.OptimizerTcpManager)
+    cs = types.ModuleType("casadi")
+    cs.__path__ = []
+    csc = types.ModuleType("casadi.casadi")
+    csc.SX = type("SX", (), {})
+    cs.casadi = csc
+    sys.modules.update({"opengen": og, "opengen.opengen": sub, "opengen.opengen.tcp": tcpm,
+                        "opengen.opengen.tcp.solver_status": ss, "casadi": cs, "casadi.casadi": csc})
+    sys.path.insert(0, "/root/reference/src")
+    try:
+        for k in ("configs", "pkg_mpc_tracker", "pkg_mpc_tracker.trajectory_tracker"):
+            sys.modules.pop(k, None)
+        ref_tt = importlib.import_module("pkg_mpc_tracker.trajectory_tracker")
+        ref_mm = importlib.import_module("basic_motion_model.motion_model")
+        fake = _Scripted()
+        mng = tcp.OptimizerTcpManager("mpc_solver/navi_fast", solver_factory=lambda: fake)
+        mng.start()
+        me = types.SimpleNamespace(mng=mng, solver=_Scripted(), use_tcp=False, nu=2, ts=0.2,
+                                   motion_model=ref_mm.UnicycleModel(0.2, rk4=True))
+        p, state = [1.5] + [0.0] * 2777, np.array([1.0, 2.0, 0.3])
+        over_tcp = ref_tt.TrajectoryTracker.run_solver_tcp(me, p, state)
+        in_proc = ref_tt.TrajectoryTracker.run_solver(me, p, state)
+        for a, b in zip(over_tcp[:3], in_proc[:3]):                  # taken_states, pred_states, actions
+            np.testing.assert_array_equal(np.array(a), np.array(b))
+        assert over_tcp[3] == in_proc[3] and over_tcp[5] == in_proc[5] == "Converged"      # cost, exit status
+        assert over_tcp[4] == 1.25                                   # solve_time_ms as the server reported it
+        with pytest.raises(RuntimeError, match=r"MPC Solver error: \[1600\]"):
+            ref_tt.TrajectoryTracker.run_solver_tcp(me, [0.0] * 5, state)
+        with pytest.raises(OSError):
+            mng.ping()                                               # the reference killed the server (:396)
+    finally:
+        sys.path.remove("/root/reference/src")
+        for k in ("configs", "pkg_mpc_tracker", "pkg_mpc_tracker.trajectory_tracker", "basic_motion_model", "basic_motion_model.motion_model"):
+            sys.modules.pop(k, None)
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
