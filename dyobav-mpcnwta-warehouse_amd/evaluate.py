@@ -101,7 +101,11 @@ class BatchEvaluator:
         self.dt = np.dtype(dtype)
         self.tdt = torch.float32 if self.dt == np.float32 else torch.float64
         self.dev = torch.device("cuda", config.device_id)
-        if config.latency_waves == 0 and (robot_starts.shape[0] > 1024 if compact is None else compact):
+        li = _capi.layout_info(config)
+        streamed = bool(li.global_table_f32 if self.dt == np.float32 else li.global_table_f64)
+        # (obstacle table streamed from global memory -- e.g. N = 40, 160 rows: the library's automatic choice there is
+        #  the cooperative kernel, whatever the batch size; pinning latency_waves would switch it off)
+        if config.latency_waves == 0 and not streamed and (robot_starts.shape[0] > 1024 if compact is None else compact):
             # The batch shrinks as scenarios finish (compaction) and the library's automatic choice between its two
             # solver kernels follows the batch size; the kernels agree to rounding only, so the choice is fixed here
             # from the initial batch: a scenario's closed-loop trajectory must not depend on who else is still running.
