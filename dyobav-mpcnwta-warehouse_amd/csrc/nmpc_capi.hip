@@ -691,6 +691,7 @@ struct Plan {
     int mode = 0;          // 0 throughput, 1 latency (speculative), 2 cooperative
     bool uses_ws = false;  // the variant reads the global obstacle workspace
     bool stageable = false;
+    int resident = 0;      // cooperative kernels: workgroups resident at once (0 = derived from the one-wavefront layout)
 };
 
 // Which solve kernel runs a batch of B instances (measured crossovers). May re-fill `k` with the layout of the
@@ -771,7 +772,12 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
     }
     pl.threads = waves ? 64 * waves : 64;
     pl.mode = coop > 1 ? 2 : waves ? 1 : 0;
-    pl.stageable = pl.mode != 2 && h->cfg.max_solver_time_us <= 0; // (one-wavefront and latency kernels park / resume)
+    pl.stageable = h->cfg.max_solver_time_us <= 0; // (every kernel family parks / resumes; a wall-clock budget does not survive it)
+    pl.resident = 0;
+    if (pl.mode == 2) { // cooperative kernels: workgroups resident on the device (LDS-bound; one per CU for the on-chip variant)
+        const int per_cu = std::max<int>(1, (int)(kLdsLimit / std::max<size_t>(pl.lds_bytes, 1)));
+        pl.resident = std::min(per_cu, std::max(1, 8 / (pl.threads / 64))) * (h->n_simd / 4);
+    }
     return pl;
 }
 
@@ -842,7 +848,10 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
     const int resident = std::max(1, std::min<int>(wpe_tp * h->n_simd,
                                                    (int)(kLdsLimit / ((size_t)L.lds_total * sizeof(T))) * (h->n_simd / 4)));
     const int lat_cap = sizeof(T) == 4 ? h->n_simd : h->n_simd / 2;
-    if (caps[0] == 0) caps[0] = ((pl.mode == 0 && B >= 4 * resident) || (pl.mode == 1 && B > lat_cap / 2 && B <= lat_cap)) ? 1 : -1;
+    if (caps[0] == 0)
+        caps[0] = ((pl.mode == 0 && B >= 4 * resident) || (pl.mode == 1 && B > lat_cap / 2 && B <= lat_cap) ||
+                   (pl.mode == 2 && !pl.uses_ws && B >= 4 * pl.resident)) ? 1 : -1; // (configs[4] fp32: 2 116 -> 2 087 ms;
+                                                                                   //  streamed table, fp64: -2 %, off)
     if (caps[1] == 0) caps[1] = -1;
     const bool stageable = allow_staging && pl.stageable && !k.order && k.status;
     int n_stage = 0, stage_cap[2], stage_key[2];

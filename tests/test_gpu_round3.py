@@ -134,6 +134,30 @@ def test_staged_latency_kernel_is_bit_identical_too(waves, axis):
             assert np.array_equal(r[k], base[k]), (staged, staged_evals, k)
 
 
+@pytest.mark.parametrize("N,Ndyn,dtype,coop", [(40, 160, np.float32, 0), (40, 160, np.float64, 0), (36, 50, np.float32, 4),
+                                               (20, 15, np.float64, 3)])
+def test_staged_cooperative_kernels_are_bit_identical_too(N, Ndyn, dtype, coop):
+    """The cooperative kernels (every wavefront of a workgroup holds the same solver state; wavefront 0 parks it, all of
+    them pick it up): the on-chip variant with helper lanes, the global-table variant in fp64, 3 and 4 wavefronts."""
+    lay = ParamLayout(N=N, Ndyn=Ndyn)
+    B = 40
+    P = nm.scenarios.make_batch(B, lay, seed=9, n_ped=3, n_hyp=4, ped_mode="oncoming").astype(dtype)
+    base = None
+    for staged in (-1, 1, 3):
+        cfg = _cfg(lay, 0, staged=staged, coop_waves=coop, latency_waves=0 if coop == 0 else 1, reg_table=0 if coop == 0 else -1,
+                   max_inner_iterations=80, max_outer_iterations=6)
+        with nm.Handle(cfg) as h:
+            r = h.solve(P)
+            li = h.last_launch_info()
+        assert li["family"] == "cooperative" and li["staged_outer_iterations"] == max(staged, 0), li
+        if base is None:
+            base = r
+            assert (r["iters"][:, 0] > 3).sum() >= B // 4
+            continue
+        for k in ("U", "cost", "status", "iters", "y", "info"):
+            assert np.array_equal(r[k], base[k]), (staged, k)
+
+
 def test_staged_solve_other_dimensions_and_automatic_choice():
     # N = 40 (one lane per step, obstacle table in the global workspace), N = 30 (two lanes per step)
     for N, Ndyn, B in ((40, 160, 48), (30, 12, 96)):
