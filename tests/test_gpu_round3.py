@@ -232,3 +232,29 @@ def test_polish_reaches_the_tight_fixed_point_and_touches_nothing_else():
     # (two continuations from two different default-tolerance end points: where the non-convex problem has several
     #  minima nearby, or a flat direction, they need not pick the same one -- the misses of both sides add up)
     assert np.median(dd) < 3e-5 and np.mean(dd < 1e-4) >= 0.55
+
+
+def test_polish_through_the_drop_in_solver_object():
+    """`solver().run(p)` (B = 1, host buffers, yaml max_solver_time honoured) with polish = 1: the answer moves to the fp64
+    fixed point when the solve converges, and nothing else about the returned object changes."""
+    from dyobav_mpcnwta_warehouse_amd.solver import Solver, make_config
+    lay = ParamLayout(N=20, Ndyn=15)
+    P = nm.scenarios.make_batch(24, lay, seed=1234, n_ped=2, n_hyp=5, ped_mode="passing")
+    plain = Solver(make_config(), dtype="float32", keep_multipliers=False)      # (independent solves: no carried state)
+    pol = Solver(make_config(polish=1), dtype="float32", keep_multipliers=False)
+    with nm.Handle(_cfg(lay, 0, tolerance=1e-8, initial_tolerance=1e-8, delta_tolerance=1e-8, max_inner_iterations=2000,
+                        max_outer_iterations=15)) as h:
+        tight = h.solve(P, dtype=np.float64)
+    moved = 0
+    for i in range(len(P)):
+        a, b = plain.run(list(P[i])), pol.run(list(P[i]))
+        assert a.exit_status == b.exit_status and len(b.solution) == 40
+        if a.exit_status != "Converged":
+            assert a.solution == b.solution
+            continue
+        assert b.num_inner_iterations > a.num_inner_iterations
+        if tight["status"][i] == 0:
+            da = np.abs(np.array(a.solution) - tight["U"][i]).max()
+            db = np.abs(np.array(b.solution) - tight["U"][i]).max()
+            moved += db < 1e-4 and db < da
+    assert moved >= 3
