@@ -26,12 +26,14 @@ print(wl, "B", B, "kernel ms", h.last_kernel_ms())
 prof = info[:, 8:].astype(np.float64)
 names = ["solver (rest: request -> eval entry)", "rollout scans+sincos", "polygons+fleet", "segments+groupmin", "ellipse slots", "pad+control+cost-sum", "adjoint",
          "solver: eval exit -> phase code", "solver: Lipschitz test + L-BFGS update", "solver: two-loop recursion", "solver: line-search test", "solver: step head"]
-tot = prof[:, :14].sum() if prof[:, 12].sum() > 0 else prof[:, :12].sum()
+coop = bool((info[:, 7] < 0).any())
+tot = prof[:, :14].sum() if coop else prof[:, :12].sum()
 ne = info[:, 4].astype(np.float64).sum(); ng = info[:, 5].astype(np.float64).sum()
 print(f"evals {ne:.3e} (grad {ng:.3e}) = {ne/B:.0f} per solve; cycles/eval total {tot/ne:.0f}")
 for i, n in enumerate(names):
     print(f"  {n:40s} {prof[:, i].sum()/tot*100:5.1f}%   {prof[:, i].sum()/ne:8.0f} ticks/eval")
-if prof[:, 12].sum() > 0:
+if coop:
     print(f"  cooperative kernel: register passes {prof[:, 13].sum()/ne:8.0f}, other rows + routing {prof[:, 12].sum()/ne:8.0f}, exchange + barrier {prof[:, 4].sum()/ne:8.0f} ticks/eval")
     sys.exit(0)
-print(f"ellipse slots visited {prof[:,13].sum():.3e}; any soft term active {prof[:,14].sum()/prof[:,13].sum()*100:.1f}%; any hard term active {prof[:,15].sum()/prof[:,13].sum()*100:.1f}%")
+print(f"ellipse passes visited {prof[:,13].sum():.3e}; any soft term active {prof[:,14].sum()/prof[:,13].sum()*100:.1f}%; any hard term active {prof[:,15].sum()/prof[:,13].sum()*100:.1f}%; "
+      f"half-passes (one slot) with a soft term in reach {prof[:,12].sum()/(2*prof[:,13].sum())*100:.1f}%")
