@@ -1223,6 +1223,9 @@ int loop_step(nmpc_handle_s* h, const nmpc_loop_args* g, bool post)
         if (!q) return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_loop_*: a required array is NULL");
     if (g->M > 0 && !g->polys) return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_loop_*: polys is NULL");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
+    // (a host pointer here would fault inside the kernel: three samples of the argument block are looked up)
+    if (h->ptr_mode != NMPC_PTR_DEVICE && (!is_device_ptr(g->robot) || !is_device_ptr(g->U_c) || !is_device_ptr(g->dyn_c)))
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_loop_*: every array must be a device pointer");
     nmpc::LoopParams<T> p;
     std::memset(&p, 0, sizeof p);
     p.B = g->B, p.n_run = g->n_run, p.N = h->cfg.N_hor, p.H = g->H, p.W = g->W, p.Lmax = g->Lmax, p.M = g->M;

@@ -264,3 +264,23 @@ def test_fused_step_kernels_against_the_torch_expressions(compact):
     # (rounding-level input differences grow along a closed loop of cap-limited solves: ~1e-3 m over a run)
     assert np.median(np.abs(a.clearance_dyn - b.clearance_dyn)[same]) < 5e-2
     assert np.median(np.abs(a.deviation - b.deviation)[same]) < 5e-2
+
+
+def test_loop_kernels_refuse_host_pointers():
+    """nmpc_loop_pre / nmpc_loop_post take device pointers only and say so instead of faulting."""
+    import ctypes as C
+    from dyobav_mpcnwta_warehouse_amd import _capi
+    with nm.Handle(nm.default_config_struct()) as h:
+        a = _capi.NmpcLoopArgs()
+        host = np.zeros(4096)
+        a.B = a.n_run = a.H = a.W = a.Lmax = 1
+        a.max_steps, a.step, a.M = 4, 0, 0
+        for name, _ in _capi.NmpcLoopArgs._fields_:
+            if name not in ("B", "n_run", "H", "W", "Lmax", "M", "step", "max_steps", "run", "base_speed", "lin_vel_max",
+                            "human_size", "human_vmax", "gather_y", "reserved", "polys", "stagger"):
+                setattr(a, name, host.ctypes.data)
+        with pytest.raises(nm.NmpcError, match="device pointer"):
+            h.loop_step(np.float64, a, post=False)
+        a.robot = None
+        with pytest.raises(nm.NmpcError, match="NULL"):
+            h.loop_step(np.float64, a, post=True)
