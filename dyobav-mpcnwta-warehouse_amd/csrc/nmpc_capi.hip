@@ -110,7 +110,10 @@ int coop_reg_rows(int N) { return kCoopRegWaves * (coop_helper_lanes(N) ? 3 * (k
 // coop_rs: layout of the cooperative register-table kernel (fp32, one lane per step): 4 x kRegSlotsCoop rows in the
 // registers of the four wavefronts, the t = 0 snapshot of all rows and the full table of the remaining rows in LDS --
 // nothing is streamed from global memory. L.rs = 0 on return if the configuration does not qualify.
-Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false)
+// reg64: layout of the fp64 register-table kernel (one wavefront per SIMD, 512 registers: 14 slots of 9 doubles = 252 of
+// them) -- offered for 13..42 provisioned rows and N <= 21; used for large batches where the 72-byte entries of the fp64
+// LDS table leave room for fewer than four instances per CU (nmpc_create decides).
+Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false, bool reg64 = false)
 {
     Layout L;
     const int N = c.N_hor;
@@ -131,6 +134,8 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false)
         if (cap <= 3 * kRegSlotsSmall) L.rs = kRegSlotsSmall;
         else if (cap <= 3 * kRegSlotsLarge) L.rs = kRegSlotsLarge;
     }
+    if (elem_size == 8 && reg64 && c.reg_table >= 0 && N <= 21 && 64 / N >= 3 && cap > 3 * kRegSlotsSmall && cap <= 3 * kRegSlotsLarge)
+        L.rs = kRegSlotsLarge;
     int left_ne = 0; // entries of the LDS table of the rows beyond the register-resident ones (cooperative register kernel)
     if (coop_rs) {
         L.rs = 0;
@@ -184,6 +189,8 @@ struct nmpc_handle_s {
     nmpc_config cfg;
     Layout lay32, lay64;
     Layout lay32c; // cooperative register-table kernel (fp32, one lane per step); rs = 0 if not available
+    Layout lay64r; // fp64 register-table kernel (three lanes per step, one wavefront per SIMD); rs = 0 if not available
+    bool use64r_auto = false; // ... chosen automatically for large batches (the LDS table allows < 4 instances per CU)
     int lps;
     int n_simd = 0; // SIMDs of the device (4 per CU): latency_waves = 0 picks the wavefront count from B / n_simd
     bool spec_ok[2] = {true, true}; // [f32, f64]
@@ -226,24 +233,30 @@ namespace {
 template <typename T, int RS>
 constexpr int wpe(int f32_default)
 {
-    return sizeof(T) == 8 ? NMPC_WPE_F64 : RS >= kRegSlotsLarge ? 2 : RS > 0 ? 3 : f32_default;
+    return sizeof(T) == 8 ? (RS > 0 ? 1 : NMPC_WPE_F64) : RS >= kRegSlotsLarge ? 2 : RS > 0 ? 3 : f32_default;
 }
 // (register-table kernels: the general and the axis-aligned variant in one kernel, see KParams::axis_mode)
 template <typename T, int LPS, int RS>
-constexpr bool kHasAxisVariant = sizeof(T) == 4 && LPS == 3 && RS > 0;
+constexpr bool kHasAxisVariant = LPS == 3 && RS > 0;
 
-template <typename T, int LPS, bool GLB, int RS = 0>
+// ONLY: 0 = both paths in one kernel (chosen per launch from KParams::axis_mode); 1 / 2 = the axis-aligned / the general
+// path alone, returning at once when the launch takes the other one. The fp64 register-table kernels are built that
+// way and launched as a pair: with both paths inlined into one 512-register kernel the compiler's output computed
+// garbage on the general path (nondeterministically, in the evaluation kernel; each path compiled alone is right).
+template <typename T, int LPS, bool GLB, int RS = 0, int ONLY = 0>
 __global__ __launch_bounds__(64, (wpe<T, RS>(NMPC_WPE_F32))) void solve_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int inst = nmpc::dispatch_index(kp);
     if constexpr (kHasAxisVariant<T, LPS, RS> && !GLB) {
-        if (nmpc::axis_path(kp)) {
+        const bool axis = nmpc::axis_path(kp);
+        if (ONLY != 0 && axis != (ONLY == 1)) return;
+        if (ONLY != 2 && axis) {
             nmpc::solve_instance<T, LPS, GLB, RS, false, false, true>(kp, inst, reinterpret_cast<T*>(smem));
             return;
         }
     }
-    nmpc::solve_instance<T, LPS, GLB, RS>(kp, inst, reinterpret_cast<T*>(smem));
+    if constexpr (ONLY != 1) nmpc::solve_instance<T, LPS, GLB, RS>(kp, inst, reinterpret_cast<T*>(smem));
 }
 
 // cooperative mode: up to kSpecWaves wavefronts per instance share every evaluation (nmpc_device.h, COOP)
@@ -309,17 +322,19 @@ __device__ __forceinline__ void eval_instance(const nmpc::KParams<T>& kp, const 
         if (ep.f2sq) ep.f2sq[inst] = f2;
     }
 }
-template <typename T, int LPS, bool GLB, int RS = 0>
-__global__ __launch_bounds__(64) void eval_kernel(nmpc::KParams<T> kp, nmpc::EvalParams<T> ep)
+template <typename T, int LPS, bool GLB, int RS = 0, int ONLY = 0>
+__global__ __launch_bounds__(64, 1) void eval_kernel(nmpc::KParams<T> kp, nmpc::EvalParams<T> ep)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if constexpr (kHasAxisVariant<T, LPS, RS> && !GLB) {
-        if (nmpc::axis_path(kp)) {
+        const bool axis = nmpc::axis_path(kp);
+        if (ONLY != 0 && axis != (ONLY == 1)) return;
+        if (ONLY != 2 && axis) {
             eval_instance<T, LPS, GLB, RS, true>(kp, ep, reinterpret_cast<T*>(smem));
             return;
         }
     }
-    eval_instance<T, LPS, GLB, RS, false>(kp, ep, reinterpret_cast<T*>(smem));
+    if constexpr (ONLY != 1) eval_instance<T, LPS, GLB, RS, false>(kp, ep, reinterpret_cast<T*>(smem));
 }
 
 // ---- small data kernels around the solves ------------------------------------------------------------------------
@@ -597,9 +612,11 @@ void (*pick_solve_coop_reg(int N))(nmpc::KParams<float>)
 template <typename T>
 SolveFn<T> pick_solve(int lps, bool glb, int rs = 0)
 {
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 4)
         if (rs == kRegSlotsSmall && lps == 3 && !glb) return solve_kernel<T, 3, false, kRegSlotsSmall>;
-        if (rs == kRegSlotsLarge && lps == 3 && !glb) return solve_kernel<T, 3, false, kRegSlotsLarge>;
+    if (rs == kRegSlotsLarge && lps == 3 && !glb) {
+        if constexpr (sizeof(T) == 8) return solve_kernel<T, 3, false, kRegSlotsLarge, 1>; // (fp64: one wavefront per SIMD; a pair)
+        else return solve_kernel<T, 3, false, kRegSlotsLarge>;
     }
     if (glb) return lps == 3 ? solve_kernel<T, 3, true> : lps == 2 ? solve_kernel<T, 2, true> : solve_kernel<T, 1, true>;
     return lps == 3 ? solve_kernel<T, 3, false> : lps == 2 ? solve_kernel<T, 2, false> : solve_kernel<T, 1, false>;
@@ -625,9 +642,11 @@ SolveFn<T> pick_solve_coop(int lps, bool glb)
 template <typename T>
 EvalFn<T> pick_eval(int lps, bool glb, int rs = 0)
 {
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 4)
         if (rs == kRegSlotsSmall && lps == 3 && !glb) return eval_kernel<T, 3, false, kRegSlotsSmall>;
-        if (rs == kRegSlotsLarge && lps == 3 && !glb) return eval_kernel<T, 3, false, kRegSlotsLarge>;
+    if (rs == kRegSlotsLarge && lps == 3 && !glb) {
+        if constexpr (sizeof(T) == 8) return eval_kernel<T, 3, false, kRegSlotsLarge, 1>;
+        else return eval_kernel<T, 3, false, kRegSlotsLarge>;
     }
     if (glb) return lps == 3 ? eval_kernel<T, 3, true> : lps == 2 ? eval_kernel<T, 2, true> : eval_kernel<T, 1, true>;
     return lps == 3 ? eval_kernel<T, 3, false> : lps == 2 ? eval_kernel<T, 2, false> : eval_kernel<T, 1, false>;
@@ -684,7 +703,7 @@ int stage_out(nmpc_handle_s* h, DevBuf& buf, T* dst, size_t count, T** dev, bool
 // ---- kernel choice and launch ---------------------------------------------------------------------------------------
 template <typename T>
 struct Plan {
-    SolveFn<T> fn = nullptr;
+    SolveFn<T> fn = nullptr, fn2 = nullptr; // fn2: the general-path twin of an axis-only kernel (fp64 register table)
     bool has_axis = false; // the kernel contains the axis-aligned variant (KParams::axis_mode)
     int threads = 64;
     size_t lds_bytes = 0;
@@ -744,7 +763,7 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
     if (L.rs > 0 || h->cfg.max_solver_time_us > 0 || !h->coop_ok[sizeof(T) == 4 ? 0 : 1]) coop = 1;
     pl.lds_bytes = (size_t)(waves ? L.lds_total_spec : L.lds_total) * sizeof(T);
     pl.fn = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs) : pick_solve<T>(h->lps, L.glb, L.rs);
-    pl.has_axis = sizeof(T) == 4 && L.rs > 0 && h->lps == 3 && !L.glb;
+    pl.has_axis = L.rs > 0 && h->lps == 3 && !L.glb;
     pl.uses_ws = L.glb;
     if (coop > 1) {
         pl.fn = pick_solve_coop<T>(h->lps, L.glb);
@@ -770,10 +789,31 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
             }
         }
     }
+    if constexpr (sizeof(T) == 8) {
+        // fp64, three lanes per step, 13..42 rows: the register-table kernel (one wavefront per SIMD, four instances per CU)
+        // where the LDS table leaves room for fewer -- measured on configs[2]'s dimensions: ahead of the latency kernel
+        // from B = 1024 on (97 vs 122 ms; 500 vs 696 ms at 8192), behind it below; never ahead for <= 12 rows, whose LDS
+        // table is small. reg_table = 1 forces it (tests), -1 switches it off.
+        const bool wanted = h->cfg.reg_table > 0 || (h->use64r_auto && B >= 2 * cap && h->cfg.latency_waves <= 1);
+        if (h->lay64r.rs > 0 && coop <= 1 && h->cfg.latency_waves <= 1 && wanted) {
+            const Layout& R = h->lay64r;
+            const nmpc::KParams<T> keep = k;
+            fill_kparams(h, k, &R);
+            k.B = keep.B, k.P = keep.P, k.U = keep.U, k.cost = keep.cost, k.status = keep.status, k.iters = keep.iters;
+            k.u0 = keep.u0, k.y = keep.y, k.y_is_input = keep.y_is_input, k.c0v = keep.c0v, k.info = keep.info;
+            k.order = keep.order;
+            waves = 0;
+            pl.fn = pick_solve<T>(h->lps, false, R.rs);
+            pl.fn2 = solve_kernel<T, 3, false, kRegSlotsLarge, 2>;
+            pl.lds_bytes = (size_t)R.lds_total * sizeof(T);
+            pl.has_axis = true;
+            pl.uses_ws = false;
+            pl.resident = h->n_simd;
+        }
+    }
     pl.threads = waves ? 64 * waves : 64;
     pl.mode = coop > 1 ? 2 : waves ? 1 : 0;
     pl.stageable = h->cfg.max_solver_time_us <= 0; // (every kernel family parks / resumes; a wall-clock budget does not survive it)
-    pl.resident = 0;
     if (pl.mode == 2) { // cooperative kernels: workgroups resident on the device (LDS-bound; one per CU for the on-chip variant)
         const int per_cu = std::max<int>(1, (int)(kLdsLimit / std::max<size_t>(pl.lds_bytes, 1)));
         pl.resident = std::min(per_cu, std::max(1, 8 / (pl.threads / 64))) * (h->n_simd / 4);
@@ -785,8 +825,14 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
 template <typename T>
 int launch_plan(nmpc_handle_s* h, const Plan<T>& pl, const nmpc::KParams<T>& k, int grid)
 {
-    hipLaunchKernelGGL(pl.fn, dim3(grid), dim3(pl.threads), pl.lds_bytes, h->stream, k);
-    HIP_TRY(hipGetLastError());
+    if (!pl.fn2 || k.axis_mode != 0) { // (axis_mode 0 = the general path only: the axis-only kernel of a pair has nothing to do)
+        hipLaunchKernelGGL(pl.fn, dim3(grid), dim3(pl.threads), pl.lds_bytes, h->stream, k);
+        HIP_TRY(hipGetLastError());
+    }
+    if (pl.fn2 && k.axis_mode != 1) {
+        hipLaunchKernelGGL(pl.fn2, dim3(grid), dim3(pl.threads), pl.lds_bytes, h->stream, k);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
@@ -849,7 +895,7 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
                                                    (int)(kLdsLimit / ((size_t)L.lds_total * sizeof(T))) * (h->n_simd / 4)));
     const int lat_cap = sizeof(T) == 4 ? h->n_simd : h->n_simd / 2;
     if (caps[0] == 0)
-        caps[0] = ((pl.mode == 0 && B >= 4 * resident) || (pl.mode == 1 && B > lat_cap / 2 && B <= lat_cap) ||
+        caps[0] = ((pl.mode == 0 && B >= 4 * (pl.resident ? pl.resident : resident)) || (pl.mode == 1 && B > lat_cap / 2 && B <= lat_cap) ||
                    (pl.mode == 2 && !pl.uses_ws && B >= 4 * pl.resident)) ? 1 : -1; // (configs[4] fp32: 2 116 -> 2 087 ms;
                                                                                    //  streamed table, fp64: -2 %, off)
     if (caps[1] == 0) caps[1] = -1;
@@ -1051,8 +1097,20 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
     if ((rc = stage_out(h, h->dgrad, grad, (size_t)B * n, &ep.grad, &hgrad))) return rc;
     if ((rc = stage_out(h, h->df2, f2sq, (size_t)B, &ep.f2sq, &hf2))) return rc;
     size_t lds_bytes = (size_t)L.lds_total * sizeof(T);
-    EvalFn<T> fn = pick_eval<T>(h->lps, L.glb, L.rs);
-    bool has_axis = sizeof(T) == 4 && L.rs > 0 && h->lps == 3 && !L.glb;
+    EvalFn<T> fn = pick_eval<T>(h->lps, L.glb, L.rs), fn2 = nullptr;
+    bool has_axis = L.rs > 0 && h->lps == 3 && !L.glb;
+    if constexpr (sizeof(T) == 8) { // (what solves of large fp64 batches run: the register-table kernel where it is offered)
+        if (h->lay64r.rs > 0 && h->cfg.coop_waves <= 1 && h->cfg.latency_waves <= 1 && (h->cfg.reg_table > 0 || h->use64r_auto)) {
+            const Layout& R = h->lay64r;
+            const nmpc::KParams<T> keep = k;
+            fill_kparams(h, k, &R);
+            k.B = keep.B, k.P = keep.P;
+            fn = pick_eval<T>(h->lps, false, R.rs);
+            fn2 = eval_kernel<T, 3, false, kRegSlotsLarge, 2>;
+            lds_bytes = (size_t)R.lds_total * sizeof(T);
+            has_axis = true;
+        }
+    }
     bool uses_ws = L.glb;
     int waves = 1;
     // coop_waves > 1: evaluate through the cooperative kernels' code path (same variant choice as solve_batch)
@@ -1086,8 +1144,14 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
     h->last_axis = has_axis ? k.axis_mode : -1;
     h->last_staged = 0;
     h->last_polish_selected = 0;
-    hipLaunchKernelGGL(fn, dim3(B), dim3(64 * waves), lds_bytes, h->stream, k, ep);
-    HIP_TRY(hipGetLastError());
+    if (!fn2 || k.axis_mode != 0) {
+        hipLaunchKernelGGL(fn, dim3(B), dim3(64 * waves), lds_bytes, h->stream, k, ep);
+        HIP_TRY(hipGetLastError());
+    }
+    if (fn2 && k.axis_mode != 1) {
+        hipLaunchKernelGGL(fn2, dim3(B), dim3(64 * waves), lds_bytes, h->stream, k, ep);
+        HIP_TRY(hipGetLastError());
+    }
     if (hpsi) HIP_TRY(hipMemcpyAsync(psi, ep.psi, (size_t)B * sizeof(T), hipMemcpyDeviceToHost, h->stream));
     if (hgrad) HIP_TRY(hipMemcpyAsync(grad, ep.grad, (size_t)B * n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
     if (hf2) HIP_TRY(hipMemcpyAsync(f2sq, ep.f2sq, (size_t)B * sizeof(T), hipMemcpyDeviceToHost, h->stream));
@@ -1431,6 +1495,9 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
     h->lay32 = make_layout(*cfg, sizeof(float));
     h->lay64 = make_layout(*cfg, sizeof(double));
     h->lay32c = make_layout(*cfg, sizeof(float), true);
+    h->lay64r = make_layout(*cfg, sizeof(double), false, true);
+    h->use64r_auto = h->lay64r.rs > 0 && !h->lay64.glb &&
+                     std::min<size_t>(4 * NMPC_WPE_F64, kLdsLimit / ((size_t)h->lay64.lds_total * sizeof(double))) < 4;
     h->lps = 64 / cfg->N_hor;
     if (h->lps > 3) h->lps = 3;
     if (h->lps < 1) h->lps = 1;

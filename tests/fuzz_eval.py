@@ -66,6 +66,7 @@ def run(cases=100, seed=0, out=print):
         B = P.shape[0]
         modes = [("one-wave", dict(coop_waves=1, reg_table=0)), ("one-wave/lds", dict(coop_waves=1, reg_table=-1)),
                  ("one-wave/general", dict(coop_waves=1, reg_table=0, axis_aligned=-1)),
+                 ("one-wave/reg64", dict(coop_waves=1, reg_table=1)),     # fp64: register-table kernel wherever it is offered
                  ("coop4", dict(coop_waves=4, reg_table=0)), ("coop4/lds", dict(coop_waves=4, reg_table=-1)),
                  ("coop%d" % (2 + ci % 2), dict(coop_waves=2 + ci % 2, reg_table=-1))]
         for dtype, tp, tg in ((np.float64, 1e-10, 1e-9), (np.float32, 2e-4, 2e-3)):

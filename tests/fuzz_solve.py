@@ -28,7 +28,7 @@ def run(cases=100, seed=0, n_outer=1, n_inner=4, out=print):
         pr = oracle.Problem(lay.N, lay.Nother, lay.Nstc, lay.Ndyn)
         op = oracle.Options(max_outer=n_outer, max_inner=n_inner, lip_delta=1e-4, lip_eps=1e-4)
         Uo, ro = oracle.solve_batch(pr, op, P, nthreads=4)
-        modes = [("throughput", dict(latency_waves=1, coop_waves=1)), ("latency%d" % (2 + ci % 3), dict(latency_waves=2 + ci % 3, coop_waves=1)),
+        modes = [("throughput", dict(latency_waves=1, coop_waves=1)), ("throughput/reg64", dict(latency_waves=1, coop_waves=1, reg_table=1)), ("latency%d" % (2 + ci % 3), dict(latency_waves=2 + ci % 3, coop_waves=1)),
                  ("coop%d" % (2 + ci % 3), dict(latency_waves=1, coop_waves=2 + ci % 3, reg_table=-1)), ("automatic", dict())]
         for name, ov in modes:
             cfg = nm.default_config_struct()
@@ -39,7 +39,7 @@ def run(cases=100, seed=0, n_outer=1, n_inner=4, out=print):
                 setattr(cfg, k, v)
             with nm.Handle(cfg) as h:
                 r = h.solve(P, dtype=np.float64)
-            key = name.rstrip("234")
+            key = name.rstrip("234") if "reg64" not in name else name
             for i in range(P.shape[0]):
                 total += 1
                 if r["iters"][i, 1] != ro["inner_iters"][i]:

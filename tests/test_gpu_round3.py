@@ -158,6 +158,54 @@ def test_staged_cooperative_kernels_are_bit_identical_too(N, Ndyn, dtype, coop):
             assert np.array_equal(r[k], base[k]), (staged, k)
 
 
+def test_fp64_register_table_kernel():
+    """fp64 with 13..42 obstacle rows and N <= 21: the register-table kernel (one wavefront per SIMD, 512 registers) -- what
+    large fp64 batches and the polish run where the 72-byte entries of the LDS table leave room for two instances per CU.
+    psi / grad psi against the oracle (both code paths), short solves step for step, staged = one launch bit for bit,
+    automatic choice by batch size."""
+    lay = ParamLayout(N=20, Ndyn=40)
+    pr = oracle.Problem(lay.N, lay.Nother, lay.Nstc, lay.Ndyn)
+    B = 16
+    rng = np.random.default_rng(3)
+    U = np.stack([rng.uniform(0.3, 1.4, (B, lay.N)), rng.uniform(-0.3, 0.3, (B, lay.N))], axis=2).reshape(B, -1)
+    Y, C = rng.normal(size=(B, 2 * lay.N)), rng.uniform(1, 300, B)
+    for rotate in (False, True):
+        P = _on_path_batch(lay, B, 12, 4, 10, rotate=rotate)
+        with nm.Handle(_cfg(lay, 40, reg_table=1, latency_waves=1, coop_waves=1)) as h:
+            r = h.eval(P, U, Y, C, dtype=np.float64)
+            assert h.last_launch_info()["axis_aligned"] == 2
+        with nm.Handle(_cfg(lay, 40, reg_table=-1, latency_waves=1, coop_waves=1)) as h:
+            r_lds = h.eval(P, U, Y, C, dtype=np.float64)
+        for i in range(B):
+            v, g = oracle.psi(pr, U[i], C[i], Y[i], P[i])
+            assert abs(r["psi"][i] - v) <= 1e-11 * max(1.0, abs(v)) and np.abs(r["grad"][i] - g).max() <= 1e-10 * max(1.0, np.abs(g).max())
+        assert np.abs(r["psi"] - r_lds["psi"]).max() <= 1e-11 * np.abs(r["psi"]).max()
+        # short solves against the oracle: same iteration counts, same controls
+        opts = oracle.Options(max_outer=1, max_inner=5, lip_delta=1e-4, lip_eps=1e-4)
+        Uo, ro = oracle.solve_batch(pr, opts, P, nthreads=4)
+        with nm.Handle(_cfg(lay, 40, reg_table=1, latency_waves=1, coop_waves=1, max_outer_iterations=1, max_inner_iterations=5,
+                            lip_eps_f64=1e-4, lip_delta_f64=1e-4)) as h:
+            s = h.solve(P, dtype=np.float64)
+            assert h.last_launch_info()["family"] == "throughput"
+        assert np.array_equal(s["iters"][:, 1], ro["inner_iters"]) and np.abs(s["U"] - Uo).max() < 1e-6
+    # resumable solve, bit for bit
+    P = nm.scenarios.make_batch(512, lay, seed=3, n_ped=4, n_hyp=10, ped_mode="passing")
+    out = []
+    for staged in (-1, 2):
+        with nm.Handle(_cfg(lay, 40, reg_table=1, latency_waves=1, coop_waves=1, staged=staged)) as h:
+            out.append(h.solve(P, dtype=np.float64))
+    for k in ("U", "cost", "status", "iters", "y", "info"):
+        assert np.array_equal(out[0][k], out[1][k]), k
+    # automatic: the latency kernel for a small batch, the register-table kernel from 1024 instances on (512 SIMD pairs)
+    with nm.Handle(_cfg(lay, 40)) as h:
+        h.solve(P[:64], dtype=np.float64)
+        assert h.last_launch_info()["family"] == "latency"
+        big = np.concatenate([P, P, P])
+        h.solve(big, dtype=np.float64)
+        li = h.last_launch_info()
+        assert li["family"] == "throughput" and li["axis_aligned"] == 2, li
+
+
 def test_staged_solve_other_dimensions_and_automatic_choice():
     # N = 40 (one lane per step, obstacle table in the global workspace), N = 30 (two lanes per step)
     for N, Ndyn, B in ((40, 160, 48), (30, 12, 96)):
