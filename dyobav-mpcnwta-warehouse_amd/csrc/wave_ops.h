@@ -256,6 +256,45 @@ __device__ __forceinline__ void class3_sum2(float& x, float& y, const int (&a)[4
     x = (x0 + x1) + (x2 + x3);
     y = (y0 + y1) + (y2 + y3);
 }
+// The same in two halves, so that independent work can sit between the crossbar requests and their results (the
+// round trip is ~130 cycles; a wavefront that waits for it does not issue, and with two wavefronts per SIMD nobody else
+// takes its slots): class3_issue() leaves the eight row partials in flight, class3_finish() adds them up.
+template <typename T>
+struct Class3Pending {
+    T x[4], y[4];
+};
+__device__ __forceinline__ void class3_issue(float x, float y, const int (&a)[4], Class3Pending<float>& p)
+{
+    asm("s_nop 0\n\t" NMPC_P2("row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+            NMPC_P2("row_shr:6 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                NMPC_P2("row_shr:12 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        : "+v"(x), "+v"(y));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p.x[q] = bperm(x, a[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p.y[q] = bperm(y, a[q]);
+}
+__device__ __forceinline__ void class3_issue(double x, double y, const int (&a)[4], Class3Pending<double>& p)
+{
+    auto rows = [](double v) {
+        v += dpp_mov<DPP_ROW_SHR0 + 3, 0xf, 0xf, true>(0.0, v);
+        v += dpp_mov<DPP_ROW_SHR0 + 6, 0xf, 0xf, true>(0.0, v);
+        v += dpp_mov<DPP_ROW_SHR0 + 12, 0xf, 0xf, true>(0.0, v);
+        return v;
+    };
+    x = rows(x);
+    y = rows(y);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p.x[q] = bperm(x, a[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p.y[q] = bperm(y, a[q]);
+}
+template <typename T>
+__device__ __forceinline__ void class3_finish(const Class3Pending<T>& p, T& x, T& y)
+{
+    x = (p.x[0] + p.x[1]) + (p.x[2] + p.x[3]);
+    y = (p.y[0] + p.y[1]) + (p.y[2] + p.y[3]);
+}
 __device__ __forceinline__ void class3_sum2(double& x, double& y, const int (&a)[4])
 {
     auto rows = [](double v) {
