@@ -37,7 +37,7 @@ def test_fp32_throughput_kernels_do_not_spill(resources):
     for name, r in _sel(resources, r"^solve_kernel<float").items():
         dual = re.search(r"<float, 3, false, (4|14), 0>", name) is not None
         assert r["sgpr_spill"] <= (32 if dual else 16), (name, r)
-        assert r["vgpr_spill"] <= (16 if dual else 0) and r["scratch"] <= (64 if dual else 0), (name, r)
+        assert r["vgpr_spill"] <= (24 if dual else 0) and r["scratch"] <= (64 if dual else 0), (name, r)
 
 
 def test_register_budgets_of_the_kernel_variants(resources):
