@@ -85,6 +85,7 @@ struct Layout {
     int lds_xch_coop, lds_total_coop; // cooperative mode: two shared parking areas, then the partial-sum exchange area
     int lds_left, lds_left_alpha;     // LDS table of the rows beyond the register-resident ones (cooperative register kernel)
     int dyn_cap;          // obstacle rows provisioned per instance
+    int table_entries;    // entries of the obstacle table the kernels index in LDS / the workspace
     int rs;               // > 0: register-resident obstacle table with this many slots per lane (LDS keeps t = 0 only)
     bool glb;             // obstacle table streamed from a global workspace instead of LDS
     long long ws_stride;  // workspace elements per instance (glb only)
@@ -144,7 +145,9 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false,
             left_ne = std::max(0, cap - coop_reg_rows(N)) * (N + 1);
         }
     }
-    int ne = L.rs ? cap + 1 : cap * (N + 1); // table entries provisioned in LDS / the workspace (register table: t = 0 rows + the dummy)
+    // table entries provisioned in LDS / the workspace. Register table: the t = 0 rows + the dummy row(s) -- three lanes per
+    // step: every row a pass can address (3 x slots), so that the passes read at fixed offsets without a clamp
+    int ne = L.rs ? std::max(cap + 1, coop_rs ? 0 : 3 * L.rs) : cap * (N + 1);
     L.dyn_cap = cap;
     L.glb = false;
     L.ws_stride = 0;
@@ -180,6 +183,7 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false,
     ne = cap * (N + 1);
     L.ws_stride = (long long)(nmpc::kEllStride + 1) * ne;
     }
+    L.table_entries = ne;
     return L;
 }
 
@@ -1439,9 +1443,8 @@ int nmpc_layout(const nmpc_config* cfg, nmpc_layout_info* out)
     out->global_table_f64 = b.glb ? 1 : 0;
     out->ws_elems_f32 = a.ws_stride;
     out->ws_elems_f64 = b.ws_stride;
-    const int N1 = cfg->N_hor + 1;
-    out->table_entries_f32 = a.rs ? a.dyn_cap + 1 : a.dyn_cap * N1;
-    out->table_entries_f64 = b.dyn_cap * N1;
+    out->table_entries_f32 = a.table_entries;
+    out->table_entries_f64 = b.table_entries;
     out->dyn_cap = a.dyn_cap;
     return 0;
 }
