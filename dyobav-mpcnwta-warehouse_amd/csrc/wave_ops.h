@@ -265,10 +265,16 @@ struct Class3Pending {
 };
 __device__ __forceinline__ void class3_issue(float x, float y, const int (&a)[4], Class3Pending<float>& p)
 {
-    asm("s_nop 0\n\t" NMPC_P2("row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-            NMPC_P2("row_shr:6 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                NMPC_P2("row_shr:12 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-        : "+v"(x), "+v"(y));
+    // (builtins here, not an asm block: with full row / bank masks the compiler folds each step into one v_add_f32_dpp
+    //  and fills the DPP wait states with the caller's independent instructions instead of s_nop)
+    auto rows = [](float v) {
+        v += dpp_mov<DPP_ROW_SHR0 + 3, 0xf, 0xf, true>(0.0f, v);
+        v += dpp_mov<DPP_ROW_SHR0 + 6, 0xf, 0xf, true>(0.0f, v);
+        v += dpp_mov<DPP_ROW_SHR0 + 12, 0xf, 0xf, true>(0.0f, v);
+        return v;
+    };
+    x = rows(x);
+    y = rows(y);
 #pragma unroll
     for (int q = 0; q < 4; ++q) p.x[q] = bperm(x, a[q]);
 #pragma unroll
