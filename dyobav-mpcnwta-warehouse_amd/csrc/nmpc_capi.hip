@@ -247,6 +247,8 @@ constexpr bool kHasAxisVariant = LPS == 3 && RS > 0;
 // path alone, returning at once when the launch takes the other one. The fp64 register-table kernels are built that
 // way and launched as a pair: with both paths inlined into one 512-register kernel the compiler's output computed
 // garbage on the general path (nondeterministically, in the evaluation kernel; each path compiled alone is right).
+// That kernel was 142 KB of code -- beyond the +-128 KB reach of s_cbranch, so its far branches were relaxed into
+// s_getpc / s_setpc sequences; tests/test_kernel_resources_cpu.py keeps every kernel below that size now.
 template <typename T, int LPS, bool GLB, int RS = 0, int ONLY = 0>
 __global__ __launch_bounds__(64, (wpe<T, RS>(NMPC_WPE_F32))) void solve_kernel(nmpc::KParams<T> kp)
 {

@@ -68,3 +68,12 @@ def test_evaluation_and_data_kernels_are_spill_free(resources):
                                                                      #  eval: SGPR -> VGPR-lane moves in the dual-path 14-slot kernel)
         for name, r in _sel(resources, pattern).items():
             assert r["sgpr_spill"] <= sgpr_budget and r["vgpr_spill"] == 0 and r["scratch"] == 0, (name, r)
+
+
+def test_every_kernel_stays_within_short_branch_range(resources):
+    # s_cbranch / s_branch reach +-32 K instructions words = 128 KB. A kernel beyond that has its far branches relaxed
+    # into s_getpc / s_add / s_setpc sequences with scavenged scalar registers -- the one kernel of this library that
+    # ever crossed the line (fp64 evaluation with both obstacle-table paths inlined, 142 KB) computed nondeterministic
+    # garbage on the far path while each path compiled alone was exact. Keep every kernel short of it.
+    for name, r in resources.items():
+        assert 0 < r["code_bytes"] < 124 * 1024, (name, r["code_bytes"])

@@ -30,6 +30,12 @@ def kernel_resources(lib=DEFAULT_LIB):
                        capture_output=True)
         notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True,
                                text=True).stdout
+        syms = subprocess.run(["nm", "-S", co], check=True, capture_output=True, text=True).stdout
+    size = {}   # mangled kernel name -> bytes of code
+    for line in syms.splitlines():
+        m = re.match(r"[0-9a-f]+ ([0-9a-f]+) [Tt] (\S+)$", line)
+        if m and not m.group(2).endswith(".kd"):
+            size[m.group(2)] = int(m.group(1), 16)
     meta = notes[notes.find("amdhsa.kernels"):]
     rows, names = {}, []
     for b in re.split(r"\n\s+- \.", meta)[1:]:
@@ -41,7 +47,8 @@ def kernel_resources(lib=DEFAULT_LIB):
         names.append(n.group(1))
         rows[n.group(1)] = dict(vgpr=g("vgpr_count"), agpr=g("agpr_count"), sgpr=g("sgpr_count"),
                                 vgpr_spill=g("vgpr_spill_count"), sgpr_spill=g("sgpr_spill_count"),
-                                scratch=g("private_segment_fixed_size"), lds_static=g("group_segment_fixed_size"))
+                                scratch=g("private_segment_fixed_size"), lds_static=g("group_segment_fixed_size"),
+                                code_bytes=size.get(n.group(1), -1))
     return {d: rows[m] for m, d in zip(names, demangle(names))}
 
 
@@ -53,4 +60,4 @@ def short_name(name):
 if __name__ == "__main__":
     for name, r in sorted(kernel_resources(*(sys.argv[1:2])).items()):
         print(f"{short_name(name):58s} vgpr {r['vgpr']:3d} agpr {r['agpr']:3d} sgpr {r['sgpr']:3d}  vgpr_spill {r['vgpr_spill']:3d}"
-              f"  sgpr_spill {r['sgpr_spill']:3d}  scratch {r['scratch']:4d} B")
+              f"  sgpr_spill {r['sgpr_spill']:3d}  scratch {r['scratch']:4d} B  code {r['code_bytes']:6d} B")
