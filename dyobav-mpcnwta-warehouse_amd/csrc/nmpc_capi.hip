@@ -148,6 +148,9 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false,
     // table entries provisioned in LDS / the workspace. Register table: the t = 0 rows + the dummy row(s) -- three lanes per
     // step: every row a pass can address (3 x slots), so that the passes read at fixed offsets without a clamp
     int ne = L.rs ? std::max(cap + 1, coop_rs ? 0 : 3 * L.rs) : cap * (N + 1);
+    // three lanes per step, register table: the table of groups of rows with identical t = 0 snapshots (nmpc_device.h,
+    // load()) takes the place of the cooperative kernel's left-over table
+    if (L.rs && !coop_rs) left_ne = 3 * L.rs;
     L.dyn_cap = cap;
     L.glb = false;
     L.ws_stride = 0;

@@ -42,6 +42,14 @@ def make_case(rng, axis_aligned=None):
             od[b, j, :, 2:4] = rng.uniform(0.2, 0.9, 2)
             od[b, j, :, 4] = rng.uniform(-1.5, 1.5) if (rng.random() < 0.7 and not axis_aligned) else 0.0
             od[b, j, :, 5] = rng.uniform(0.0, 1.0, N + 1)
+    # hypotheses of one pedestrian share their t = 0 snapshot (what the reference's producer writes): in half of the
+    # cases the rows are dealt into a few groups with identical (x, y, rx, ry, angle) at t = 0 and their own weights --
+    # the kernels merge such rows for the t = 0 terms
+    if rows >= 2 and rng.random() < 0.5:
+        n_groups = int(rng.integers(1, max(2, rows // 2 + 1)))
+        leaders = slots[:n_groups]
+        for j in slots[n_groups:]:
+            od[:, j, 0, 0:5] = od[:, leaders[int(rng.integers(0, n_groups))], 0, 0:5]
     P[:, lay.od:lay.od + od[0].size] = od.reshape(B, -1)
     # fleet: some robots with non-zero positions near the path
     for j in range(1, Nother):
