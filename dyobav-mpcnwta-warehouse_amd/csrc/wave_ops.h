@@ -66,19 +66,24 @@ __device__ __forceinline__ double read_lane(double x, int lane)
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-// ---- f32 reductions / scans: each step is x += dpp(x) as ONE VALU instruction (v_add_f32_dpp); hipcc lowers
-//      update_dpp + add to v_mov (old) + s_nop + v_mov_dpp + v_add, and pads every separate asm statement with
-//      its own s_nop, so a whole chain is written as one asm block. "s_nop 1" = the 2 wait states a DPP read
-//      needs after a VALU write of the same VGPR; in the 2-/3-way versions the other chains fill those slots.
+// ---- f32 reductions / scans: each step is x += dpp(x) as ONE VALU instruction (v_add_f32_dpp). Steps with full row and
+//      bank masks go through update_dpp builtins: the compiler folds mov + add into v_add_f32_dpp (with
+//      -fno-slp-vectorize) and fills the two wait states a DPP read needs after a VALU write of the same register with
+//      the caller's independent instructions, inserting s_nop only where none is at hand. Steps with partial row masks
+//      (row_bcast) would come out as v_mov (old) + v_mov_dpp + v_add: those are asm blocks with their own s_nop.
 
 // Sum over the 64 lanes; the result is wave-uniform (read back from lane 63 into scalar registers).
 __device__ __forceinline__ float wave_sum(float x)
 {
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"     // row sums everywhere
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"    // rows 1,3 += rows 0,2
+    // The four in-row steps (full row / bank masks) through builtins: the compiler folds each into one v_add_f32_dpp and
+    // fills the two wait states a dependent DPP read needs with whatever independent instructions the caller has (the
+    // two-loop recursion: the next pair's LDS read, slot arithmetic, the alpha bookkeeping) instead of s_nop. The two
+    // cross-row steps have partial row masks -- there it would emit v_mov + v_mov_dpp + v_add -- and stay an asm block.
+    x += dpp_mov<DPP_QUAD_1032, 0xf, 0xf, true>(0.0f, x);
+    x += dpp_mov<DPP_QUAD_2301, 0xf, 0xf, true>(0.0f, x);
+    x += dpp_mov<DPP_ROW_HALF_MIRROR, 0xf, 0xf, true>(0.0f, x);
+    x += dpp_mov<DPP_ROW_MIRROR, 0xf, 0xf, true>(0.0f, x);                                   // row sums everywhere
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"    // rows 1,3 += rows 0,2
         "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"        // rows 2,3 += rows 0+1
         : "+v"(x));
     return read_lane(x, 63);
@@ -100,11 +105,16 @@ __device__ __forceinline__ double wave_sum(double x)
     "v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl "\n\t"
 __device__ __forceinline__ void wave_sum2(float x, float y, float& sx, float& sy)
 {
-    asm("s_nop 0\n\t" NMPC_P2("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-            NMPC_P2("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-                NMPC_P2("row_half_mirror row_mask:0xf bank_mask:0xf") NMPC_P2("row_mirror row_mask:0xf bank_mask:0xf")
-                    NMPC_P2("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                        NMPC_P2("row_bcast:31 row_mask:0xc bank_mask:0xf")
+    // (in-row steps through builtins, cross-row steps in one asm block: see wave_sum)
+    x += dpp_mov<DPP_QUAD_1032, 0xf, 0xf, true>(0.0f, x);
+    y += dpp_mov<DPP_QUAD_1032, 0xf, 0xf, true>(0.0f, y);
+    x += dpp_mov<DPP_QUAD_2301, 0xf, 0xf, true>(0.0f, x);
+    y += dpp_mov<DPP_QUAD_2301, 0xf, 0xf, true>(0.0f, y);
+    x += dpp_mov<DPP_ROW_HALF_MIRROR, 0xf, 0xf, true>(0.0f, x);
+    y += dpp_mov<DPP_ROW_HALF_MIRROR, 0xf, 0xf, true>(0.0f, y);
+    x += dpp_mov<DPP_ROW_MIRROR, 0xf, 0xf, true>(0.0f, x);
+    y += dpp_mov<DPP_ROW_MIRROR, 0xf, 0xf, true>(0.0f, y);
+    asm("s_nop 0\n\t" NMPC_P2("row_bcast:15 row_mask:0xa bank_mask:0xf") NMPC_P2("row_bcast:31 row_mask:0xc bank_mask:0xf")
         : "+v"(x), "+v"(y));
     sx = read_lane(x, 63);
     sy = read_lane(y, 63);
@@ -157,11 +167,11 @@ __device__ __forceinline__ void wave_sum3(double x, double y, double z, double& 
 // Inclusive prefix sum over lanes 0..63 (lane i gets x_0 + ... + x_i).
 __device__ __forceinline__ float wave_scan_incl(float x)
 {
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+    x += dpp_mov<DPP_ROW_SHR0 + 1, 0xf, 0xf, true>(0.0f, x);
+    x += dpp_mov<DPP_ROW_SHR0 + 2, 0xf, 0xf, true>(0.0f, x);
+    x += dpp_mov<DPP_ROW_SHR0 + 4, 0xf, 0xf, true>(0.0f, x);
+    x += dpp_mov<DPP_ROW_SHR0 + 8, 0xf, 0xf, true>(0.0f, x);
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
         "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
         : "+v"(x));
     return x;
@@ -169,12 +179,15 @@ __device__ __forceinline__ float wave_scan_incl(float x)
 // two prefix sums with interleaved chains
 __device__ __forceinline__ void wave_scan_incl2(float& x, float& y)
 {
-    asm("s_nop 0\n\t" NMPC_P2("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-            NMPC_P2("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                NMPC_P2("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                    NMPC_P2("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                        NMPC_P2("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                            NMPC_P2("row_bcast:31 row_mask:0xc bank_mask:0xf")
+    x += dpp_mov<DPP_ROW_SHR0 + 1, 0xf, 0xf, true>(0.0f, x);
+    y += dpp_mov<DPP_ROW_SHR0 + 1, 0xf, 0xf, true>(0.0f, y);
+    x += dpp_mov<DPP_ROW_SHR0 + 2, 0xf, 0xf, true>(0.0f, x);
+    y += dpp_mov<DPP_ROW_SHR0 + 2, 0xf, 0xf, true>(0.0f, y);
+    x += dpp_mov<DPP_ROW_SHR0 + 4, 0xf, 0xf, true>(0.0f, x);
+    y += dpp_mov<DPP_ROW_SHR0 + 4, 0xf, 0xf, true>(0.0f, y);
+    x += dpp_mov<DPP_ROW_SHR0 + 8, 0xf, 0xf, true>(0.0f, x);
+    y += dpp_mov<DPP_ROW_SHR0 + 8, 0xf, 0xf, true>(0.0f, y);
+    asm("s_nop 0\n\t" NMPC_P2("row_bcast:15 row_mask:0xa bank_mask:0xf") NMPC_P2("row_bcast:31 row_mask:0xc bank_mask:0xf")
         : "+v"(x), "+v"(y));
 }
 __device__ __forceinline__ double wave_scan_incl(double x)
@@ -208,20 +221,22 @@ __device__ __forceinline__ T wave_suffix_fix_rows(T x)
 }
 __device__ __forceinline__ float wave_scan_suffix_incl(float x)
 {
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0"
-        : "+v"(x));
+    x += dpp_mov<0x100 + 1, 0xf, 0xf, true>(0.0f, x); // row_shl:n = 0x100 + n
+    x += dpp_mov<0x100 + 2, 0xf, 0xf, true>(0.0f, x);
+    x += dpp_mov<0x100 + 4, 0xf, 0xf, true>(0.0f, x);
+    x += dpp_mov<0x100 + 8, 0xf, 0xf, true>(0.0f, x);
     return wave_suffix_fix_rows(x);
 }
 __device__ __forceinline__ void wave_scan_suffix_incl2(float& x, float& y)
 {
-    asm("s_nop 0\n\t" NMPC_P2("row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-            NMPC_P2("row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                NMPC_P2("row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-                    NMPC_P2("row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
-        : "+v"(x), "+v"(y));
+    x += dpp_mov<0x100 + 1, 0xf, 0xf, true>(0.0f, x);
+    y += dpp_mov<0x100 + 1, 0xf, 0xf, true>(0.0f, y);
+    x += dpp_mov<0x100 + 2, 0xf, 0xf, true>(0.0f, x);
+    y += dpp_mov<0x100 + 2, 0xf, 0xf, true>(0.0f, y);
+    x += dpp_mov<0x100 + 4, 0xf, 0xf, true>(0.0f, x);
+    y += dpp_mov<0x100 + 4, 0xf, 0xf, true>(0.0f, y);
+    x += dpp_mov<0x100 + 8, 0xf, 0xf, true>(0.0f, x);
+    y += dpp_mov<0x100 + 8, 0xf, 0xf, true>(0.0f, y);
     x = wave_suffix_fix_rows(x);
     y = wave_suffix_fix_rows(y);
 }
