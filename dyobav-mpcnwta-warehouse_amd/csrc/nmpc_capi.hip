@@ -183,6 +183,7 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false,
     if (L.glb || (size_t)L.lds_total * elem_size <= kLdsLimit) break;
     L.glb = true; // second attempt: everything but the ellipse table in LDS
     L.rs = 0;     // (the GLB kernels index the full [row][t] table: the register-table layout does not apply)
+    left_ne = 0;
     ne = cap * (N + 1);
     L.ws_stride = (long long)(nmpc::kEllStride + 1) * ne;
     }
