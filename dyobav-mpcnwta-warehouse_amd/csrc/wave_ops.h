@@ -215,8 +215,14 @@ __device__ __forceinline__ T wave_suffix_fix_rows(T x)
     int l = (int)(threadIdx.x & 63);
     asm volatile("" : "+v"(l)); // (opaque: keeps the three row masks from being hoisted into long-lived SGPR pairs)
     const int row = l >> 4;
-    const T s23 = t2 + t3, s123 = t1 + s23;
-    const T add = row == 0 ? s123 : row == 1 ? s23 : row == 2 ? t3 : T(0);
+    // The three candidates as finished per-lane values before the selection: left to itself the compiler turns the
+    // chain of conditions into divergent branches (exec masking, ~20 instructions) to avoid computing sums a row does
+    // not need; as plain selects it is three compares and three v_cndmask.
+    T c3 = t3, c23 = t2 + t3, c123 = t1 + c23;
+    asm volatile("" : "+v"(c3), "+v"(c23), "+v"(c123));
+    T add = row == 2 ? c3 : T(0);
+    add = row == 1 ? c23 : add;
+    add = row == 0 ? c123 : add;
     return x + add;
 }
 __device__ __forceinline__ float wave_scan_suffix_incl(float x)
