@@ -10,19 +10,20 @@ control sequences are all-gathered over RCCL -- the only collective on this path
 configs[2] (batch=65536 main_eva.py scenarios, N=20, 4 obstacles x 10 hypotheses, fp32) -- the per-GPU shard of
 configs[3] (8 x 65536, seeds 1..8), so the N = 1, 2, 4, 8 series of the metric is one family.
 
-Rank 0 prints ONE JSON line with the driver's keys plus
-  roofline     : HBM roofline of the solve kernel (algorithmic bytes / HIP-event kernel time) -- this path is
-                 VALU/latency bound, so the HBM fraction is tiny by construction; the fp32 vector-ALU figure that
-                 actually bounds it is reported next to it as the flat keys roofline.valu_tflops / valu_frac /
-                 psi_evals_per_solve
-  solver       : convergence statistics of the timed batch, split into converged / not converged instances
-  secondary    : (N = 1) the other BASELINE configurations -- configs[1] (B = 1024), configs[4] (N = 40, fp32) -- and
-                 the `passing` scenario family of configs[2], where the solver converges, each with its own rate
-  cpu_baseline : the CPU oracle (plain-C restatement of the reference's OpEn algorithm, kind "port") timed on
-                 this box's host cores on a bounded sample of the same batch (N = 1, rank 0 only), and the result of
-                 probing the box for a genuine OpEn toolchain (cargo + opengen + casadi)
-  accuracy     : (N = 1) SURVEY.md 8(d) accuracy protocol (tests/accuracy_protocol.py) on small seeded samples of the
-                 configs[1] / [2] / [4] generators.
+Rank 0 prints ONE COMPACT JSON line (< 4 KB aimed at, < 8 KB asserted: round 3's 21.7 KB line was not parsed by the
+driver) with the driver's keys plus
+  roofline               : HBM roofline of the solve kernel (algorithmic bytes / HIP-event kernel time) -- this path is
+                           VALU/latency bound, so the HBM fraction is tiny by construction; the fp32 vector-ALU figure
+                           that actually bounds it sits next to it as roofline.valu_tflops / valu_frac / psi_evals_per_solve
+  converged_frac         : share of the timed instances that end Converged
+  secondary_solves_per_s : (N = 1) flat {name: solves/s} of the other BASELINE configurations, the `passing` scenario
+                           family (where the solver converges), fp64, polish and dispatch-hint rows
+  cpu_baseline           : the CPU oracle (plain-C restatement of the reference's OpEn algorithm, kind "port") timed on
+                           this box's host cores on a bounded sample of the same batch (N = 1, rank 0 only)
+  accuracy_summary       : (N = 1) flat {name: number} digest of the SURVEY.md 8(d) accuracy protocol
+                           (tests/accuracy_protocol.py) on small seeded samples of the configs[1] / [2] / [4] generators
+and writes everything it measured, un-abridged (solver statistics, every secondary row, the whole accuracy table, the
+CPU-baseline notes), to `bench_detail.json` next to this file and to stderr.
 """
 from __future__ import annotations
 
@@ -207,19 +208,26 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
     waves = int(info[0, 7])          # 0: throughput kernel; > 0: latency kernel with that many wavefronts per instance
     tname = "float" if dtype == "f32" else "double"
     lps = kinfo["lanes_per_step"]
-    kernel_name = (f"solve_spec_kernel<{tname}, LPS={lps}> x {waves} wavefronts per instance (latency mode)" if waves > 0
-                   else f"solve_coop_kernel<{tname}, LPS={lps}> x {-waves} wavefronts sharing each evaluation" if waves < 0
-                   else f"solve_kernel<{tname}, LPS={lps}> (one wavefront per instance)")
+    # short name for the line (matches the rocprofv3 kernel-trace name up to the template tail); prose in bench_detail.json
+    kernel_name = (f"solve_spec_kernel<{tname},{lps}> W={waves}" if waves > 0
+                   else f"solve_coop_kernel<{tname},{lps}> W={-waves}" if waves < 0
+                   else f"solve_kernel<{tname},{lps}>")
+    kernel_desc = ("latency mode: several wavefronts per instance, speculative line search" if waves > 0
+                   else "cooperative: the wavefronts of a workgroup share each evaluation" if waves < 0
+                   else "one wavefront per instance")
     flops_launch = float(np.sum((n_psi - n_grad) * ff + n_grad * 3 * ff))
     achieved_tf = flops_launch / (k_ms * 1e-3) / 1e12
     conv = status == 0
     if launch["axis_aligned"] == 2:
-        kernel_name += " [axis-aligned variant + general twin enqueued, chosen on the device]"
+        kernel_name += " axis"
+        kernel_desc += "; axis-aligned code path chosen on the device"
     if launch["staged_outer_iterations"]:
-        kernel_name += f" [two launches: pilot of {launch['staged_outer_iterations']} outer iteration(s), rest ranked by ||F2||]"
+        kernel_name += " x2 launches"
+        kernel_desc += f"; two launches: pilot of {launch['staged_outer_iterations']} outer iteration(s), rest ranked by ||F2||"
     polished = None
     if polish:
-        kernel_name += " + fp64 polish of the converged instances"
+        kernel_name += " +polish64"
+        kernel_desc += "; fp64 polish of the converged instances"
         polished = {"selected": launch["polish_selected"], "replaced": int((info[:, 6] == 1).sum()),
                     "kept_main_result": int((info[:, 6] == 2).sum())}
 
@@ -245,7 +253,7 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
         # / peak fp32 vector rate), flat so that they survive any consumer that keeps scalars only
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(workload, dtype, B),
-                     "kernel": kernel_name, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_per_solve * B,
+                     "kernel": kernel_name, "kernel_description": kernel_desc, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_per_solve * B,
                      "binding_roofline": "fp32 VALU issue (see valu_*), HBM fraction is tiny by construction",
                      "valu_tflops": achieved_tf, "valu_peak_tflops": VALU_PEAK_TFLOPS,
                      "valu_frac": achieved_tf / VALU_PEAK_TFLOPS, "flops_per_psi_eval": ff,
@@ -293,7 +301,7 @@ def main(argv=None, env_factory=Env):
     gathered = m.pop("_gathered")
 
     if env.rank == 0:
-        out = {
+        detail = {
             "metric": f"MPC solves/sec (N={layout.N}, batched)",
             "value": m["value"],
             "unit": "solves/s",
@@ -316,17 +324,121 @@ def main(argv=None, env_factory=Env):
         }
         single = env.world == 1
         if single and not args.no_secondary:
-            out["secondary"] = secondary_workloads(env, args)
+            detail["secondary"] = secondary_workloads(env, args)
         if single and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(layout, P_host)
+            detail["cpu_baseline"] = cpu_baseline(layout, P_host)
         if single and not args.no_accuracy:
-            out["accuracy"] = accuracy_table(env)
-        result_out.write(json.dumps(out) + "\n")
+            detail["accuracy"] = accuracy_table(env)
+        line = compact_line(detail)
+        try:                                       # the un-abridged record: a side file + stderr, never stdout
+            with open(os.path.join(ROOT, "bench_detail.json"), "w") as f:
+                json.dump(detail, f, indent=1)
+        except OSError as exc:
+            print(f"[bench] bench_detail.json not written: {exc!r}", file=sys.stderr)
+        print("[bench detail] " + json.dumps(detail), file=sys.stderr)
+        result_out.write(line + "\n")
         result_out.flush()
 
     if env.use_dist:
         env.dist.destroy_process_group()
     return {"U": U, "gathered": gathered, "P_checksum": float(np.abs(P_host).sum())}
+
+
+LINE_TARGET_BYTES, LINE_LIMIT_BYTES = 4096, 8192
+
+
+def _r(x, sig=5):
+    """floats to `sig` significant digits (the line is a digest; bench_detail.json keeps full precision)"""
+    if isinstance(x, (bool, np.bool_)):
+        return bool(x)
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        if x != x or x in (float("inf"), float("-inf")):
+            return None                      # strict JSON only
+        return float(f"{x:.{sig}g}")
+    return x
+
+
+def secondary_key(row) -> str:
+    """flat name of a secondary row: workload[_b<batch override>]_family_dtype[_polish][_hint]"""
+    w = row["workload"].split(":")[0]
+    fam = "" if row["family"] == "toward_robot" else "_" + row["family"]
+    b = f"_b{row['batch']}" if row.get("batch_override") else ""
+    return f"{w}{b}{fam}_{row['dtype']}" + ("_polish" if row.get("polish") else "") + \
+        ("_hint" if row["dispatch"] != "index order" else "")
+
+
+def accuracy_digest(acc) -> dict:
+    """{name: number}: per (workload, family) the comparisons that carry the parity / accuracy statement -- median AND
+    max next to the share below the north star's 1e-4."""
+    out = {}
+    for row in acc.get("rows", []):
+        pre = f"{row['workload']}_{row['family']}_"
+        for cmp_, short in (("hip64_vs_oracle64", "hip64_vs_oracle64"), ("hip64_vs_oracle64_tight", "hip64_vs_oracle64_tol1e-8"),
+                            ("oracle64_vs_reassociated", "oracle64_vs_oracle64reassoc")):
+            st = row.get(cmp_)
+            if not st:
+                continue
+            out[pre + short + "_same_status"] = _r(st["same_status_frac"], 3)
+            if st.get("both_converged"):
+                out[pre + short + "_n_both_conv"] = st["both_converged"]
+                out[pre + short + "_median"] = _r(st["median_abs_du_both_converged"], 2)
+                out[pre + short + "_max"] = _r(st["max_abs_du_both_converged"], 2)
+                out[pre + short + "_frac_lt_1e-4"] = _r(st["frac_lt_1e-4_both_converged"], 3)
+        for cmp_, short in (("hip32_vs_hip64_tight", "hip32_vs_fixedpoint"), ("hip32polish_vs_hip64_tight", "hip32polish_vs_fixedpoint"),
+                            ("hip32polish_vs_hip64polish", "hip32polish_vs_hip64polish")):
+            st = row.get(cmp_)
+            if not st or not st.get("n"):
+                continue
+            out[pre + short + "_n"] = st["n"]
+            out[pre + short + "_median"] = _r(st["median_abs_du"], 2)
+            out[pre + short + "_max"] = _r(st["max_abs_du"], 2)
+            out[pre + short + "_frac_lt_1e-4"] = _r(st["frac_lt_1e-4"], 3)
+        if row.get("divergence_audit"):
+            a = row["divergence_audit"]
+            out[pre + "audit_pairs_gt_1e-4"] = a["n_pairs"]
+            out[pre + "audit_split_at_discrete_tie"] = a["n_tie"]
+            out[pre + "audit_unexplained"] = a["n_unexplained"]
+    return out
+
+
+def compact_line(detail: dict) -> str:
+    """The ONE stdout line: driver keys, `roofline`, `cpu_baseline` and flat digests -- numbers, no prose. Optional parts
+    are dropped (largest first) should the line ever exceed LINE_TARGET_BYTES; above LINE_LIMIT_BYTES is an error."""
+    keep_cfg = ("workload", "family", "batch_per_gpu", "N_hor", "Ndynobs", "Nstcobs", "Nother", "np", "dispatch", "sharding")
+    keep_roof = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_launch",
+                 "valu_tflops", "valu_peak_tflops", "valu_frac", "psi_evals_per_solve", "flops_per_psi_eval")
+    out = {k: _r(detail[k], 9) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                         "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = {k: detail["config"][k] for k in keep_cfg if k in detail["config"]}
+    out["roofline"] = {k: _r(detail["roofline"][k], 6) for k in keep_roof if k in detail["roofline"]}
+    out["converged_frac"] = _r(detail["converged_frac"])
+    out["converged_solves_per_s"] = _r(detail["converged_solves_per_s"])
+    if "cpu_baseline" in detail:
+        cb = detail["cpu_baseline"]
+        out["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind", "sample", "single_core_value",
+                                                      "value_with_reference_time_cap", "converged_frac", "open_probe")
+                               if k in cb}
+    if "secondary" in detail:
+        out["secondary_solves_per_s"] = {secondary_key(r): _r(r["value"], 4) for r in detail["secondary"]}
+    if "accuracy" in detail:
+        out["accuracy_summary"] = accuracy_digest(detail["accuracy"])
+    out["detail"] = "bench_detail.json"
+    line = json.dumps(out, separators=(",", ":"), allow_nan=False)
+    for victim in ("accuracy_summary", "secondary_solves_per_s"):
+        if len(line) <= LINE_TARGET_BYTES or victim not in out:
+            continue
+        if victim == "accuracy_summary":        # first thin it out: keep the parity / north-star keys only
+            out[victim] = {k: v for k, v in out[victim].items()
+                           if k.endswith(("_max", "_frac_lt_1e-4", "_unexplained")) and "passing" in k}
+        else:
+            del out[victim]
+        line = json.dumps(out, separators=(",", ":"), allow_nan=False)
+    if len(line) > LINE_LIMIT_BYTES:
+        raise RuntimeError(f"bench line is {len(line)} bytes (> {LINE_LIMIT_BYTES}): the driver would not parse it")
+    return line
 
 
 def secondary_workloads(env: Env, args) -> list:
@@ -356,6 +468,7 @@ def secondary_workloads(env: Env, args) -> list:
         r.pop("_host")
         r.pop("_gathered")
         res.append({"workload": r["config"]["workload"], "family": family, "dtype": dtype, "note": note,
+                    "batch_override": bool(batch),
                     "polish": r["polish"],
                     "psi_evals_per_solve": r["roofline"]["psi_evals_per_solve"],
                     "dispatch": r["config"]["dispatch"], "value": r["value"],
@@ -442,8 +555,7 @@ def cpu_baseline(layout, P_host):
             "note": "fp64 restatement run to its iteration caps: the reference's own solver would be cut off at its "
                     "max_solver_time (0.1 s per solve, mpc_builder.py:189) -- at %.0f ms per solve on one core most of "
                     "these solves would end NotConvergedOutOfTime there. Reported, not a target." % (1e3 * t_one / n1),
-            "sample": f"first {sample} instances of the timed batch, fp64 oracle, OpenMP over instances "
-                      f"({t_all:.2f} s wall)",
+            "sample": f"first {sample} instances of the timed batch, fp64, {t_all:.1f} s wall",
             "single_core_value": n1 / t_one, "single_core_sample": f"first {n1} instances, 1 thread",
             "value_with_reference_time_cap": sample / t_cap,
             "reference_time_cap": {"max_solver_time_s": cap_s, "wall_s": t_cap,
