@@ -258,6 +258,7 @@ __global__ __launch_bounds__(64, (wpe<T, RS>(NMPC_WPE_F32))) void solve_kernel(n
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int inst = nmpc::dispatch_index(kp);
+    if (nmpc::finished_in_pilot<T>(inst)) return;
     if constexpr (kHasAxisVariant<T, LPS, RS> && !GLB) {
         const bool axis = nmpc::axis_path(kp);
         if (ONLY != 0 && axis != (ONLY == 1)) return;
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(64 * kSpecWaves, (sizeof(T) == 4 ? NMPC_SPEC_WPE_F3
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int inst = nmpc::dispatch_index(kp);
+    if (nmpc::finished_in_pilot<T>(inst)) return;
     nmpc::solve_instance<T, LPS, GLB, 0, true>(kp, inst, reinterpret_cast<T*>(smem));
 }
 // ... with the obstacle table on chip instead of in global memory, for one lane per horizon step (N > 32), where it does
@@ -284,6 +286,7 @@ __global__ __launch_bounds__(64 * kCoopRegWaves, 2) void solve_coop_reg_kernel(n
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int inst = nmpc::dispatch_index(kp);
+    if (nmpc::finished_in_pilot<float>(inst)) return;
     nmpc::solve_instance<float, 1, false, kRegSlotsCoop, true, HLP>(kp, inst, reinterpret_cast<float*>(smem));
 }
 
@@ -293,6 +296,7 @@ __global__ __launch_bounds__(64 * kSpecWaves, (wpe<T, RS>(NMPC_SPEC_WPE_F32))) v
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int inst = nmpc::dispatch_index(kp);
+    if (nmpc::finished_in_pilot<T>(inst)) return;
     if constexpr (kHasAxisVariant<T, LPS, RS> && !GLB) {
         if (nmpc::axis_path(kp)) {
             nmpc::solve_instance_spec<T, LPS, GLB, RS, true>(kp, inst, reinterpret_cast<T*>(smem));
@@ -500,16 +504,11 @@ __global__ __launch_bounds__(64) void selftest_kernel(int* fails)
     if (bad) atomicOr(fails, bad);
 }
 
+// The layout-dependent fields only (parameter offsets, LDS map): what a kernel choice that brings its own layout re-fills,
+// leaving the batch buffers and -- ADVICE r3 -- the solver options of the caller (the polish's tolerances and caps) alone.
 template <typename T>
-void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k, const Layout* layout = nullptr)
+void fill_layout(nmpc::KParams<T>& k, const Layout& L)
 {
-    const nmpc_config& c = h->cfg;
-    const Layout& L = layout ? *layout : h->lay<T>();
-    std::memset(&k, 0, sizeof k);
-    k.N = c.N_hor;
-    k.Nother = c.Nother;
-    k.Nstc = c.Nstcobs;
-    k.Ndyn = c.Ndynobs;
     k.np = L.np;
     k.dyn_cap = L.dyn_cap;
     k.off_rs = L.off_rs;
@@ -534,6 +533,18 @@ void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k, const Layout* lay
     k.lds_park = L.lds_park;
     k.lds_left = L.lds_left;
     k.lds_left_alpha = L.lds_left_alpha;
+}
+
+template <typename T>
+void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k, const Layout* layout = nullptr)
+{
+    const nmpc_config& c = h->cfg;
+    std::memset(&k, 0, sizeof k);
+    fill_layout(k, layout ? *layout : h->lay<T>());
+    k.N = c.N_hor;
+    k.Nother = c.Nother;
+    k.Nstc = c.Nstcobs;
+    k.Ndyn = c.Ndynobs;
     k.ts = (T)c.ts;
     k.inv_ts = (T)(1.0 / c.ts);
     k.vmin = (T)c.lin_vel_min;
@@ -787,11 +798,7 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
             if (coop == kSpecWaves && h->lay32c.rs > 0 && h->lps == 1) {
                 waves = kCoopRegWaves;
                 const Layout& C = h->lay32c;
-                const nmpc::KParams<T> keep = k;
-                fill_kparams(h, k, &C);
-                k.B = keep.B, k.P = keep.P, k.U = keep.U, k.cost = keep.cost, k.status = keep.status, k.iters = keep.iters;
-                k.u0 = keep.u0, k.y = keep.y, k.y_is_input = keep.y_is_input, k.c0v = keep.c0v, k.info = keep.info;
-                k.order = keep.order;
+                fill_layout(k, C);
                 k.lds_xch = C.lds_xch_coop;
                 pl.fn = pick_solve_coop_reg(h->cfg.N_hor);
                 pl.lds_bytes = (size_t)C.lds_total_coop * sizeof(T);
@@ -807,11 +814,7 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
         const bool wanted = h->cfg.reg_table > 0 || (h->use64r_auto && B >= 2 * cap && h->cfg.latency_waves <= 1);
         if (h->lay64r.rs > 0 && coop <= 1 && h->cfg.latency_waves <= 1 && wanted) {
             const Layout& R = h->lay64r;
-            const nmpc::KParams<T> keep = k;
-            fill_kparams(h, k, &R);
-            k.B = keep.B, k.P = keep.P, k.U = keep.U, k.cost = keep.cost, k.status = keep.status, k.iters = keep.iters;
-            k.u0 = keep.u0, k.y = keep.y, k.y_is_input = keep.y_is_input, k.c0v = keep.c0v, k.info = keep.info;
-            k.order = keep.order;
+            fill_layout(k, R);
             waves = 0;
             pl.fn = pick_solve<T>(h->lps, false, R.rs);
             pl.fn2 = solve_kernel<T, 3, false, kRegSlotsLarge, 2>;
@@ -1112,9 +1115,7 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
     if constexpr (sizeof(T) == 8) { // (what solves of large fp64 batches run: the register-table kernel where it is offered)
         if (h->lay64r.rs > 0 && h->cfg.coop_waves <= 1 && h->cfg.latency_waves <= 1 && (h->cfg.reg_table > 0 || h->use64r_auto)) {
             const Layout& R = h->lay64r;
-            const nmpc::KParams<T> keep = k;
-            fill_kparams(h, k, &R);
-            k.B = keep.B, k.P = keep.P;
+            fill_layout(k, R);
             fn = pick_eval<T>(h->lps, false, R.rs);
             fn2 = eval_kernel<T, 3, false, kRegSlotsLarge, 2>;
             lds_bytes = (size_t)R.lds_total * sizeof(T);
@@ -1133,9 +1134,7 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
         if constexpr (sizeof(T) == 4) {
             if (waves == kSpecWaves && h->lay32c.rs > 0 && h->lps == 1) {
                 const Layout& C = h->lay32c;
-                const nmpc::KParams<T> keep = k;
-                fill_kparams(h, k, &C);
-                k.B = keep.B, k.P = keep.P;
+                fill_layout(k, C);
                 k.lds_xch = C.lds_xch_coop;
                 waves = kCoopRegWaves;
                 fn = pick_eval_coop_reg(h->cfg.N_hor);

@@ -439,7 +439,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 }
             }
             if (finished) {
-                if (!converged) status = out_of_time ? 2 : 1;
+                if (!converged) status = (out_of_time || !cont_time) ? 2 : 1;
                 bool finite = tfinite(uv) && tfinite(uw) && tfinite(f_u);
                 if (__ballot(!finite) != 0ull) status = 3;
                 if (wv == 0) {

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(64) void loop_pre_kernel(LoopParams<T> p)
         const int i = e / 3, c = e - 3 * i;
         long long r = idx + i;
         r = r < len - 1 ? r : len - 1;
+        r = r < 0 ? 0 : r < p.Lmax ? r : p.Lmax - 1; // (device-side ref_len outside [1, Lmax]: stay inside the row)
         p.refs_c[(size_t)a * 3 * N + e] = rt[3 * r + c];
     }
     if (lane == 0) {

@@ -101,6 +101,14 @@ class BatchEvaluator:
         self.dt = np.dtype(dtype)
         self.tdt = torch.float32 if self.dt == np.float32 else torch.float64
         self.dev = torch.device("cuda", config.device_id)
+        if config.axis_aligned == 0:
+            # the pedestrians' obstacle rows are written here with angle = 0 (main_base.py:302), so the promise can be
+            # made once instead of leaving the code path to the per-call scan of the batch (nmpc_hip.h, axis_aligned:
+            # with 0 the path -- and with it the last bits of every result -- depends on the batch composition)
+            import copy
+            config = copy.copy(config)
+            config.axis_aligned = 1
+            self.cfg = config
         li = _capi.layout_info(config)
         streamed = bool(li.global_table_f32 if self.dt == np.float32 else li.global_table_f64)
         # (obstacle table streamed from global memory -- e.g. N = 40, 160 rows: the library's automatic choice there is

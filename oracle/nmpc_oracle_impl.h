@@ -675,6 +675,8 @@ int SUF(orc_solve)(const orc_problem *pr, const orc_options *op, const REAL *p, 
         int inner_status = SUF(panoc_solve)(&cx, pc, u, op->max_inner, &inner_iters, &last_fpr, t_end);
         inner_total += inner_iters;
         status = inner_status;
+        if (inner_status == 2) out_of_time = 1; /* the clock ran out inside this inner solve (also when it was the last
+                                                   outer iteration: the exit status is OutOfTime, not Iterations) */
         /* update_lagrange_multipliers: y+ = y + c [F1(u) - Proj_C(F1(u) + y/c)] ; F2 norm */
         SUF(core)(pr, u, 0, 0, p, 0, F1, F2, 0, 0);
         for (int i = 0; i < n1; ++i) {

@@ -94,21 +94,31 @@ def test_dispatch_order_changes_nothing_but_the_launch_time():
     cfg = nm.default_config_struct()
     cfg.N_hor, cfg.Ndynobs, cfg.max_active_dynobs = 20, 40, 40
     cfg.latency_waves = 1
+    cfg.staged = -1           # one launch in plain index order: the baseline the orders below are compared with (the
+                              # automatic two-launch solve ranks its second launch itself and would blur the comparison)
+
+    def timed(h):             # median of three launches: a bare inequality on one launch is noise-prone
+        ts = []
+        for _ in range(3):
+            h.solve(P)
+            ts.append(h.last_kernel_ms())
+        return float(np.median(ts))
+
     with nm.Handle(cfg) as h:
         base = h.solve(P)
-        t_base = min(h.last_kernel_ms() for _ in range(2) if h.solve(P) is not None)
+        t_base = timed(h)
         rng = np.random.default_rng(0)
         h.set_dispatch_order(rng.permutation(B).astype(np.int32))
         shuffled = h.solve(P)
         lpt = np.argsort(-base["info"][:, 4], kind="stable").astype(np.int32)
         h.set_dispatch_order(lpt)
         first = h.solve(P)
-        t_lpt = min(h.last_kernel_ms() for _ in range(2) if h.solve(P) is not None)
+        t_lpt = timed(h)
         import torch
         h.set_dispatch_order(torch.from_numpy(lpt[::-1].copy()).cuda())      # device-resident order: shortest first
         torch.cuda.synchronize()
         last = h.solve(P)
-        t_spt = h.last_kernel_ms()
+        t_spt = timed(h)
         with pytest.raises(nm.NmpcError):
             h.set_dispatch_order(np.zeros(B, np.int32))                     # not a permutation
         h.set_dispatch_order(None)
@@ -119,7 +129,9 @@ def test_dispatch_order_changes_nothing_but_the_launch_time():
         for k in ("U", "cost", "status", "iters", "info"):
             assert np.array_equal(r[k], base[k]), k
     print(f"kernel ms: index order {t_base:.1f}, longest first {t_lpt:.1f}, shortest first {t_spt:.1f}")
-    assert t_lpt < t_base and t_spt > t_lpt      # (at this batch size the longest instance alone is ~90 % of the launch)
+    # (round 3 measured 156 -> 94 ms for 'longest first' on this family at B = 65 536; at this batch size the longest instance
+    #  alone is most of the launch, so the margin asked for is a modest one)
+    assert t_lpt < 0.97 * t_base and t_spt > 1.03 * t_lpt, (t_base, t_lpt, t_spt)
 
 
 def test_latency_kernel_results_do_not_depend_on_the_wavefront_count():

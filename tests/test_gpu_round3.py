@@ -282,6 +282,45 @@ def test_polish_reaches_the_tight_fixed_point_and_touches_nothing_else():
     assert np.median(dd) < 3e-5 and np.mean(dd < 1e-4) >= 0.55
 
 
+def test_polish_keeps_its_tolerances_on_the_fp64_register_table_kernel():
+    """when the polish's compact fp64 batch is run by the fp64 register-table kernel (configs[2]
+    dimensions: Ndyn = 40 rows; automatic from 1024 selected instances on, forced here with reg_table = 1), the kernel
+    choice used to re-fill every solver option from the handle's configuration -- the continuation then ran at the MAIN
+    tolerance (1e-4), 'converged' at once and overwrote the result with itself. The continuation must run at
+    polish_tolerance on that path too: distance to the 1e-8 fixed point as on the LDS-table path."""
+    lay = ParamLayout(N=20, Ndyn=40)
+    B = 384
+    P = nm.scenarios.make_batch(B, lay, seed=1234, n_ped=4, n_hyp=10, ped_mode="passing")
+    P32 = P.astype(np.float32)
+    with nm.Handle(_cfg(lay, 40)) as h:
+        plain = h.solve(P32)
+    res = {}
+    for name, rt in (("reg64", 1), ("lds64", -1)):
+        with nm.Handle(_cfg(lay, 40, polish=1, reg_table=rt)) as h:
+            res[name] = h.solve(P32)
+            assert h.last_launch_info()["polish_selected"] == int((plain["status"] == 0).sum())
+    with nm.Handle(_cfg(lay, 40, tolerance=1e-8, initial_tolerance=1e-8, delta_tolerance=1e-8, max_inner_iterations=2000,
+                        max_outer_iterations=15)) as h:
+        tight = h.solve(P, dtype=np.float64)
+    du_plain = np.abs(plain["U"].astype(np.float64) - tight["U"]).max(axis=1)
+    for name, pol in res.items():
+        done = pol["info"][:, 6] == 1
+        both = done & (tight["status"] == 0)
+        du = np.abs(pol["U"].astype(np.float64) - tight["U"]).max(axis=1)
+        extra = (pol["info"][done, 4] - plain["info"][done, 4]).mean()
+        print(f"{name}: polished {done.sum()} of {(plain['status'] == 0).sum()}, {extra:.0f} extra evaluations each; vs fp64 at "
+              f"1e-8: median {np.median(du[both]):.2e} (unpolished {np.median(du_plain[both]):.2e}), < 1e-4: {np.mean(du[both] < 1e-4):.2f}")
+        assert both.sum() >= 40, name
+        assert np.median(du[both]) < 3e-5 and np.mean(du[both] < 1e-4) >= 0.75, name
+        assert np.median(du_plain[both]) > 3e-4
+        # a continuation at tolerance 1e-6 costs evaluations: the broken path got away with ~50 per instance
+        assert extra > 100, (name, extra)
+    # the two table layouts run the same algorithm at the same tolerances: same continuations to solver accuracy
+    d = np.abs(res["reg64"]["U"].astype(np.float64) - res["lds64"]["U"].astype(np.float64)).max(axis=1)
+    sel = (res["reg64"]["info"][:, 6] == 1) & (res["lds64"]["info"][:, 6] == 1)
+    assert np.median(d[sel]) < 1e-5
+
+
 def test_polish_through_the_drop_in_solver_object():
     """`solver().run(p)` (B = 1, host buffers, yaml max_solver_time honoured) with polish = 1: the answer moves to the fp64
     fixed point when the solve converges, and nothing else about the returned object changes."""
