@@ -401,6 +401,8 @@ def accuracy_digest(acc) -> dict:
             out[pre + "audit_pairs_gt_1e-4"] = a["n_pairs"]
             out[pre + "audit_split_at_discrete_tie"] = a["n_tie"]
             out[pre + "audit_unexplained"] = a["n_unexplained"]
+            out[pre + "audit_oracle_vs_reassoc_pairs"] = a["oracle_vs_reassociated"]["n_pairs"]
+            out[pre + "audit_oracle_vs_reassoc_unexplained"] = a["oracle_vs_reassociated"]["n_unexplained"]
     return out
 
 
@@ -432,7 +434,8 @@ def compact_line(detail: dict) -> str:
             continue
         if victim == "accuracy_summary":        # first thin it out: keep the parity / north-star keys only
             out[victim] = {k: v for k, v in out[victim].items()
-                           if k.endswith(("_max", "_frac_lt_1e-4", "_unexplained")) and "passing" in k}
+                           if k.endswith(("_max", "_frac_lt_1e-4", "_unexplained", "_pairs_gt_1e-4")) and "passing" in k
+                           and "hip32polish_vs_hip64polish" not in k}
         else:
             del out[victim]
         line = json.dumps(out, separators=(",", ":"), allow_nan=False)
@@ -582,8 +585,11 @@ def accuracy_table(env: Env) -> dict:
                 skipped.append(f"{workload}/{family}")
                 continue
             rows.append(accuracy_protocol.run_case(env.nm, oracle, workload, family, nthreads=cores,
-                                                   tight=(family == "passing" and workload != "cfg4")))
-    return {"protocol": "HIP fp64 vs oracle fp64 with the same Lipschitz-estimator step (1e-4) at default tolerance / caps "
+                                                   tight=(family == "passing" and workload != "cfg4"),
+                                                   audit=(family == "passing" and workload != "cfg4"), audit_max=12))
+    return {"protocol": "oracle64_vs_reassociated = the oracle's own noise floor (same fp64 algorithm, sums associated differently); "
+                        "divergence_audit = iteration traces of every pair > 1e-4 apart laid side by side; "
+                        "HIP fp64 vs oracle fp64 with the same Lipschitz-estimator step (1e-4) at default tolerance / caps "
                         "and (family `passing`, configs[1] and [2]; configs[4] in tests/test_gpu_accuracy.py) at tolerance 1e-8 with caps 2000 x 15; HIP fp32 vs HIP fp64; "
                         "|du| = max_i |u_i - u_ref_i| per instance", "rows": rows, "skipped_for_time": skipped,
             "seconds": time.perf_counter() - t0}

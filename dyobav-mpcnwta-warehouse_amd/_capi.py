@@ -82,7 +82,7 @@ class NmpcLoopArgs(C.Structure):
 EXPORTED_SYMBOLS = (
     "nmpc_default_config", "nmpc_layout", "nmpc_create", "nmpc_destroy", "nmpc_param_len", "nmpc_set_stream", "nmpc_use_own_stream", "nmpc_set_pointer_mode",
     "nmpc_set_dispatch_order",
-    "nmpc_solve_batch_f32", "nmpc_solve_batch_f64", "nmpc_eval_batch_f32", "nmpc_eval_batch_f64",
+    "nmpc_solve_batch_f32", "nmpc_solve_batch_f64", "nmpc_solve_trace_f64", "nmpc_eval_batch_f32", "nmpc_eval_batch_f64",
     "nmpc_assemble_params_f32", "nmpc_assemble_params_f64",
     "nmpc_hypotheses_to_ellipses_f32", "nmpc_hypotheses_to_ellipses_f64",
     "nmpc_loop_pre_f32", "nmpc_loop_pre_f64", "nmpc_loop_post_f32", "nmpc_loop_post_f64",
@@ -134,6 +134,7 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
                                                                        C.c_double, C.c_double, i32, vp, vp]
         getattr(lib, "nmpc_loop_pre_" + sfx).argtypes = [vp, C.POINTER(NmpcLoopArgs)]
         getattr(lib, "nmpc_loop_post_" + sfx).argtypes = [vp, C.POINTER(NmpcLoopArgs)]
+    lib.nmpc_solve_trace_f64.argtypes = [vp, vp, vp, vp, C.c_double, vp, vp, vp, vp, vp, vp, i32, C.POINTER(i32)]
     lib.nmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.nmpc_kernel_info.argtypes = [vp] + [C.POINTER(i32)] * 5
     lib.nmpc_last_launch_info.argtypes = [vp, C.POINTER(i32 * 8)]
@@ -327,6 +328,27 @@ class Handle:
         info = np.empty((B, 8), dtype=dtype) if want_info else None
         self.solve_raw(dtype, P, B, U, cost, status, iters, u0, y, y0 is not None, c0, info, True)
         return dict(U=U, cost=cost, status=status, iters=iters, y=y, info=info)
+
+    def solve_trace(self, p, u0=None, y0=None, c0=None, max_records=None) -> dict:
+        """``nmpc_solve_trace_f64``: one instance through the one-wavefront fp64 kernel with its iteration trace --
+        ``head[n_rec, 16]`` (fields as in ``include/nmpc_hip.h``) and ``Ut[n_rec, 2N]``, the iterate after each inner
+        iteration. Diagnostic (first-divergence audit against the oracle's trace)."""
+        p = np.ascontiguousarray(p, dtype=np.float64).reshape(-1)
+        if p.size != self.np_:
+            raise ValueError(f"p must have {self.np_} entries, got {p.size}")
+        n = self.n
+        max_records = int(max_records or self.cfg.max_outer_iterations * (self.cfg.max_inner_iterations + 1))
+        u0 = None if u0 is None else np.ascontiguousarray(u0, dtype=np.float64).reshape(n)
+        y0 = None if y0 is None else np.ascontiguousarray(y0, dtype=np.float64).reshape(n)
+        U, y = np.empty(n), np.empty(n)
+        status, iters, info = np.empty(1, np.int32), np.empty(2, np.int32), np.empty(8)
+        tr = np.zeros((max_records, 16 + n))
+        nrec = C.c_int32(0)
+        q = _Arg.ptr
+        _check(self._lib.nmpc_solve_trace_f64(self._h, q(p), q(u0), q(y0), float(c0 or 0.0), q(U), q(y), q(status), q(iters),
+                                              q(info), q(tr), max_records, C.byref(nrec)))
+        tr = tr[:nrec.value]
+        return dict(U=U, y=y, status=int(status[0]), iters=iters, info=info, head=tr[:, :16].copy(), Ut=tr[:, 16:].copy())
 
     def eval(self, P: np.ndarray, U: np.ndarray, Y: np.ndarray, Cpen: np.ndarray, grad=True, dtype=None) -> dict:
         dtype = np.dtype(dtype or P.dtype)

@@ -270,6 +270,14 @@ __global__ __launch_bounds__(64, (wpe<T, RS>(NMPC_WPE_F32))) void solve_kernel(n
     if constexpr (ONLY != 1) nmpc::solve_instance<T, LPS, GLB, RS>(kp, inst, reinterpret_cast<T*>(smem));
 }
 
+// diagnostic: the one-wavefront fp64 solver (LDS / global table) writing one record per inner iteration (KParams::trace)
+template <int LPS, bool GLB>
+__global__ __launch_bounds__(64, NMPC_WPE_F64) void trace_kernel(nmpc::KParams<double> kp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    nmpc::solve_instance<double, LPS, GLB, 0, false, false, false, true>(kp, (int)blockIdx.x, reinterpret_cast<double*>(smem));
+}
+
 // cooperative mode: up to kSpecWaves wavefronts per instance share every evaluation (nmpc_device.h, COOP)
 template <typename T, int LPS, bool GLB>
 __global__ __launch_bounds__(64 * kSpecWaves, (sizeof(T) == 4 ? NMPC_SPEC_WPE_F32 : NMPC_WPE_F64)) void solve_coop_kernel(nmpc::KParams<T> kp)
@@ -1086,6 +1094,78 @@ int polish_batch(nmpc_handle_s* h, const nmpc::KParams<T>& k, int B, bool y_user
     return 0;
 }
 
+// nmpc_solve_trace_f64: ONE instance (host pointers) through trace_kernel; see include/nmpc_hip.h
+int solve_trace(nmpc_handle_s* h, const double* p, const double* u0, const double* y0, double c0, double* U, double* y,
+                int32_t* status, int32_t* iters, double* info, double* trace, int32_t max_records, int32_t* n_records)
+{
+    if (!h) return fail(NMPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (!p || !U || !trace || !n_records || max_records < 1)
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "p, U, trace, n_records must not be NULL and max_records >= 1");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const Layout& L = h->lay64;
+    const size_t n = 2 * (size_t)h->cfg.N_hor, np = L.np;
+    const size_t rec = (size_t)nmpc::kTraceHead + n, tlen = (size_t)nmpc::kTraceHead + (size_t)max_records * rec;
+    nmpc::KParams<double> k;
+    fill_kparams(h, k);
+    k.B = 1;
+    int rc;
+    struct Scoped : DevBuf { // (local buffers: freed on every path out of this function)
+        ~Scoped() { release(); }
+    } dtrace, dc0;
+    if ((rc = dtrace.reserve(tlen * sizeof(double)))) return rc;
+    if ((rc = h->dP.reserve(np * sizeof(double)))) return rc;
+    if ((rc = h->dU.reserve(n * sizeof(double)))) return rc;
+    if ((rc = h->dy.reserve(n * sizeof(double)))) return rc;
+    if ((rc = h->du0.reserve(n * sizeof(double)))) return rc;
+    if ((rc = h->dcost.reserve(sizeof(double)))) return rc;
+    if ((rc = h->dstatus.reserve(sizeof(int32_t)))) return rc;
+    if ((rc = h->diters.reserve(2 * sizeof(int32_t)))) return rc;
+    if ((rc = h->dinfo.reserve(8 * sizeof(double)))) return rc;
+    if ((rc = dc0.reserve(sizeof(double)))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->dP.p, p, np * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (u0) HIP_TRY(hipMemcpyAsync(h->du0.p, u0, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (y0) HIP_TRY(hipMemcpyAsync(h->dy.p, y0, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (c0 > 0) HIP_TRY(hipMemcpyAsync(dc0.p, &c0, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(dtrace.p, 0, nmpc::kTraceHead * sizeof(double), h->stream));
+    k.P = static_cast<const double*>(h->dP.p);
+    k.u0 = u0 ? static_cast<const double*>(h->du0.p) : nullptr;
+    k.y = static_cast<double*>(h->dy.p);
+    k.y_is_input = y0 != nullptr;
+    k.c0v = c0 > 0 ? static_cast<const double*>(dc0.p) : nullptr;
+    k.U = static_cast<double*>(h->dU.p);
+    k.cost = static_cast<double*>(h->dcost.p);
+    k.status = static_cast<int*>(h->dstatus.p);
+    k.iters = static_cast<int*>(h->diters.p);
+    k.info = static_cast<double*>(h->dinfo.p);
+    k.trace = static_cast<double*>(dtrace.p);
+    k.trace_cap = max_records;
+    k.time_budget = 0;
+    if (L.glb) {
+        if ((rc = h->dws.reserve((size_t)L.ws_stride * sizeof(double)))) return rc;
+        k.ws = static_cast<double*>(h->dws.p);
+        k.ws_stride = L.ws_stride;
+    }
+    using Fn = void (*)(nmpc::KParams<double>);
+    const Fn fn = L.glb ? (h->lps == 3 ? (Fn)trace_kernel<3, true> : h->lps == 2 ? (Fn)trace_kernel<2, true> : (Fn)trace_kernel<1, true>)
+                        : (h->lps == 3 ? (Fn)trace_kernel<3, false> : h->lps == 2 ? (Fn)trace_kernel<2, false> : (Fn)trace_kernel<1, false>);
+    const size_t lds_bytes = (size_t)L.lds_total * sizeof(double);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(fn, dim3(1), dim3(64), lds_bytes, h->stream, k);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(U, k.U, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (y) HIP_TRY(hipMemcpyAsync(y, k.y, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (status) HIP_TRY(hipMemcpyAsync(status, k.status, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (iters) HIP_TRY(hipMemcpyAsync(iters, k.iters, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (info) HIP_TRY(hipMemcpyAsync(info, k.info, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    std::vector<double> host(tlen);
+    HIP_TRY(hipMemcpyAsync(host.data(), dtrace.p, tlen * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int nr = (int)host[0];
+    *n_records = nr;
+    std::memcpy(trace, host.data() + nmpc::kTraceHead, (size_t)nr * rec * sizeof(double));
+    return 0;
+}
+
 template <typename T>
 int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C, int32_t B, T* psi, T* grad,
                T* f2sq)
@@ -1627,6 +1707,13 @@ int nmpc_solve_batch_f64(nmpc_handle h, const double* P, int32_t B, double* U, d
                          double* info, int32_t sync)
 {
     return solve_batch<double>(h, P, B, U, cost, status, iters, u0, y, y_is_input, c0, info, sync);
+}
+
+int nmpc_solve_trace_f64(nmpc_handle h, const double* p, const double* u0, const double* y0, double c0, double* U, double* y,
+                         int32_t* status, int32_t* iters, double* info, double* trace, int32_t max_records,
+                         int32_t* n_records)
+{
+    return solve_trace(h, p, u0, y0, c0, U, y, status, iters, info, trace, max_records, n_records);
 }
 
 int nmpc_eval_batch_f32(nmpc_handle h, const float* P, const float* U, const float* Y, const float* C, int32_t B,

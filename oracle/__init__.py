@@ -138,8 +138,18 @@ class Options:
                         self.cbfgs_alpha, self.cbfgs_eps, self.sy_eps, self.akkt_form, 0, self.max_time_s)
 
 
-def _suffix(dtype) -> str:
+TRACE_HEAD = 16   # ORC_TRACE_HEAD
+TRACE_FIELDS = ("outer", "iter", "lip_doublings", "ls_halvings", "pair", "pairs_held", "gamma", "norm_gfpr", "psi", "tau",
+                "n_cost", "n_grad", "margin", "margin_kind", "penalty", "_")
+MARGIN_KINDS = {0: "-", 1: "lipschitz", 2: "linesearch", 3: "pair", 4: "exit"}
+
+
+def _suffix(dtype, reassoc: bool = False) -> str:
     dtype = np.dtype(dtype)
+    if reassoc:
+        if dtype != np.float64:
+            raise TypeError("the re-associated variant exists in double precision only")
+        return "r64"
     if dtype == np.float64:
         return "f64"
     if dtype == np.float32:
@@ -164,7 +174,7 @@ def eval_problem(pr: Problem, u, p, dtype=np.float64):
     return float(f[0]), F1, F2
 
 
-def psi(pr: Problem, u, c, y, p, grad=True, dtype=np.float64):
+def psi(pr: Problem, u, c, y, p, grad=True, dtype=np.float64, reassoc=False):
     u = np.ascontiguousarray(u, dtype=dtype)
     p = np.ascontiguousarray(p, dtype=dtype)
     y = np.ascontiguousarray(y, dtype=dtype)
@@ -173,27 +183,50 @@ def psi(pr: Problem, u, c, y, p, grad=True, dtype=np.float64):
     g = np.zeros(2 * pr.N, dtype=dtype) if grad else None
     cp = pr.c()
     cc = C.c_double(c) if np.dtype(dtype) == np.float64 else C.c_float(c)
-    getattr(lib(), "orc_psi_" + _suffix(dtype))(C.byref(cp), _ptr(u), cc, _ptr(y), _ptr(p), _ptr(val),
+    getattr(lib(), "orc_psi_" + _suffix(dtype, reassoc))(C.byref(cp), _ptr(u), cc, _ptr(y), _ptr(p), _ptr(val),
                                                  _ptr(g) if grad else None)
     return float(val[0]), g
 
 
-def solve(pr: Problem, op: Options, p, u0=None, y0=None, dtype=np.float64):
-    """One ALM/PANOC solve. Returns (u, y, result-record)."""
+def solve(pr: Problem, op: Options, p, u0=None, y0=None, dtype=np.float64, reassoc=False):
+    """One ALM/PANOC solve. Returns (u, y, result-record). `reassoc`: the same fp64 algorithm with its sums associated
+    differently (nmpc_oracle_impl.h, ORC_REASSOC)."""
     p = np.ascontiguousarray(p, dtype=dtype)
     assert p.size == pr.np_
     u = np.zeros(2 * pr.N, dtype=dtype) if u0 is None else np.array(u0, dtype=dtype)
     y = np.zeros(2 * pr.N, dtype=dtype) if y0 is None else np.array(y0, dtype=dtype)
     res = np.zeros(1, dtype=RESULT_DTYPE)
     cp, co = pr.c(), op.c()
-    rc = getattr(lib(), "orc_solve_" + _suffix(dtype))(C.byref(cp), C.byref(co), _ptr(p), _ptr(u), _ptr(y),
-                                                        _ptr(res))
+    rc = getattr(lib(), "orc_solve_" + _suffix(dtype, reassoc))(C.byref(cp), C.byref(co), _ptr(p), _ptr(u), _ptr(y),
+                                                                 _ptr(res))
     if rc != 0:
         raise RuntimeError(f"oracle solve failed rc={rc}")
     return u, y, res[0]
 
 
-def solve_batch(pr: Problem, op: Options, P, nthreads: int = 1, dtype=np.float64):
+def solve_trace(pr: Problem, op: Options, p, u0=None, y0=None, dtype=np.float64, reassoc=False, max_records=None):
+    """One solve with its iteration trace: (u, y, result-record, head[n_rec, 16], U[n_rec, 2N]) -- one record per completed
+    inner iteration (fields: TRACE_FIELDS; nmpc_oracle.h), U = the iterate after it."""
+    p = np.ascontiguousarray(p, dtype=dtype)
+    assert p.size == pr.np_
+    n = 2 * pr.N
+    u = np.zeros(n, dtype=dtype) if u0 is None else np.array(u0, dtype=dtype)
+    y = np.zeros(n, dtype=dtype) if y0 is None else np.array(y0, dtype=dtype)
+    res = np.zeros(1, dtype=RESULT_DTYPE)
+    max_records = max_records or op.max_outer * (op.max_inner + 1)
+    tr = np.zeros((max_records, TRACE_HEAD + n), dtype=np.float64)
+    nrec = C.c_int(0)
+    cp, co = pr.c(), op.c()
+    rc = getattr(lib(), "orc_solve_trace_" + _suffix(dtype, reassoc))(C.byref(cp), C.byref(co), _ptr(p), _ptr(u), _ptr(y),
+                                                                       _ptr(res), _ptr(tr), C.c_int(max_records),
+                                                                       C.byref(nrec))
+    if rc != 0:
+        raise RuntimeError(f"oracle solve failed rc={rc}")
+    tr = tr[:nrec.value]
+    return u, y, res[0], tr[:, :TRACE_HEAD].copy(), tr[:, TRACE_HEAD:].copy()
+
+
+def solve_batch(pr: Problem, op: Options, P, nthreads: int = 1, dtype=np.float64, reassoc=False):
     """Independent solves (zero initial guess / multipliers), OpenMP over instances."""
     P = np.ascontiguousarray(P, dtype=dtype)
     assert P.ndim == 2 and P.shape[1] == pr.np_
@@ -201,7 +234,7 @@ def solve_batch(pr: Problem, op: Options, P, nthreads: int = 1, dtype=np.float64
     U = np.zeros((B, 2 * pr.N), dtype=dtype)
     res = np.zeros(B, dtype=RESULT_DTYPE)
     cp, co = pr.c(), op.c()
-    rc = getattr(lib(), "orc_solve_batch_" + _suffix(dtype))(C.byref(cp), C.byref(co), _ptr(P), C.c_int(B),
+    rc = getattr(lib(), "orc_solve_batch_" + _suffix(dtype, reassoc))(C.byref(cp), C.byref(co), _ptr(P), C.c_int(B),
                                                               _ptr(U), _ptr(res), C.c_int(nthreads))
     if rc != 0:
         raise RuntimeError(f"oracle batch solve failed rc={rc}")

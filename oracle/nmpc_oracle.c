@@ -81,6 +81,25 @@ static inline int risfinite_f32(float x) { return isfinite(x); }
 #undef REAL_MIN_POS
 #undef REAL_EPS
 
+/* ---------------- double, sums re-associated (see ORC_REASSOC in nmpc_oracle_impl.h) ---------------- */
+#define ORC_REASSOC 1
+#define REAL double
+#define SUF(x) x##_r64
+#define REAL_MIN_POS DBL_MIN
+#define REAL_EPS DBL_EPSILON
+static inline double rcos_r64(double x) { return cos(x); }
+static inline double rsin_r64(double x) { return sin(x); }
+static inline double rsqrt_r64(double x) { return sqrt(x); }
+static inline double rabs_r64(double x) { return fabs(x); }
+static inline double rpow_r64(double x, double y) { return pow(x, y); }
+static inline int risfinite_r64(double x) { return isfinite(x); }
+#include "nmpc_oracle_impl.h"
+#undef REAL
+#undef SUF
+#undef REAL_MIN_POS
+#undef REAL_EPS
+#undef ORC_REASSOC
+
 /* ---------------- primitives for the known-answer tests ---------------- */
 double orc_dist2_to_lineseg(double px, double py, double ax, double ay, double bx, double by)
 {

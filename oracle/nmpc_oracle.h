@@ -106,6 +106,31 @@ int orc_solve_f64(const orc_problem *pr, const orc_options *op, const double *p,
 int orc_solve_f32(const orc_problem *pr, const orc_options *op, const float *p, float *u, float *y,
                   orc_result *res);
 
+/* The same double-precision solver with its sums associated differently (reverse accumulation order, rollout as
+ * X0 + running sum): same algorithm, same decisions rules, different rounding -- the oracle's own noise floor under
+ * re-association (tests/accuracy_protocol.py). */
+void orc_psi_r64(const orc_problem *pr, const double *u, double c, const double *y, const double *p,
+                 double *psi, double *grad);
+int orc_solve_r64(const orc_problem *pr, const orc_options *op, const double *p, double *u, double *y,
+                  orc_result *res);
+int orc_solve_batch_r64(const orc_problem *pr, const orc_options *op, const double *P, int B, double *U,
+                        orc_result *res, int nthreads);
+
+/* Iteration trace of one solve (first-divergence audit, tests/accuracy_protocol.py): like orc_solve_*, plus one record
+ * of ORC_TRACE_HEAD + 2N doubles per completed inner iteration, up to max_rec records:
+ *   [0] outer iteration (1-based)  [1] inner iteration index within it  [2] Lipschitz doublings  [3] line-search halvings
+ *   [4] L-BFGS pair: -1 not tested / 0 rejected / 1 accepted  [5] pairs in the buffer  [6] gamma  [7] ||gamma fpr||
+ *   [8] psi at the new iterate  [9] tau  [10] cost evaluations so far  [11] gradient evaluations so far
+ *   [12] smallest relative margin of the iteration's discrete decisions  [13] which: 1 Lipschitz test, 2 line-search
+ *   test, 3 pair acceptance, 4 exit test  [14] penalty c  [15] -  [16..] u after the iteration */
+#define ORC_TRACE_HEAD 16
+int orc_solve_trace_f64(const orc_problem *pr, const orc_options *op, const double *p, double *u, double *y,
+                        orc_result *res, double *trace, int max_rec, int *n_rec);
+int orc_solve_trace_r64(const orc_problem *pr, const orc_options *op, const double *p, double *u, double *y,
+                        orc_result *res, double *trace, int max_rec, int *n_rec);
+int orc_solve_trace_f32(const orc_problem *pr, const orc_options *op, const float *p, float *u, float *y,
+                        orc_result *res, double *trace, int max_rec, int *n_rec);
+
 /* Batch of independent solves (zero initial guess, zero multipliers), OpenMP over instances. */
 int orc_solve_batch_f64(const orc_problem *pr, const orc_options *op, const double *P, int B, double *U,
                         orc_result *res, int nthreads);

@@ -13,6 +13,18 @@
 #error "include from nmpc_oracle.c"
 #endif
 
+/* ORC_REASSOC (third instantiation, suffix _r64): THE SAME ALGORITHM IN THE SAME PRECISION WITH ITS SUMS ASSOCIATED
+ * DIFFERENTLY -- inner products and the accumulations over obstacles / polygons / robots run in reverse index order, the
+ * two obstacle snapshots swap places, the rollout positions are X0 + (running sum of the increments) instead of a chain
+ * of additions onto X. No decision rule, constant or tie-break differs (the segment minimum keeps "first wins"). It
+ * exists to measure how far two correct fp64 implementations of this solver end up from each other (the oracle's own
+ * noise floor under re-association: tests/accuracy_protocol.py). */
+#ifdef ORC_REASSOC
+#define ORC_IDX(i, n) ((n) - 1 - (i))
+#else
+#define ORC_IDX(i, n) (i)
+#endif
+
 #define ORC_MAXN 64                 /* max horizon supported by the oracle   */
 #define ORC_MAXNV (2 * ORC_MAXN)    /* max number of decision variables      */
 #define ORC_MAXDYN 512
@@ -105,7 +117,8 @@ static void SUF(stage)(const orc_problem *pr, const SUF(offs) * o, const REAL *p
 
     /* --- fleet collision, other robots at t=0: robots 1..Nother-1 only, weight 1000
      *     (mpc_builder.py:86-90: the strided slice starts at ns; mpc_cost.py:65-76) */
-    for (int j = 1; j < pr->Nother; ++j) {
+    for (int jj = 1; jj < pr->Nother; ++jj) {
+        const int j = 1 + ORC_IDX(jj - 1, pr->Nother - 1);
         REAL dx = x - p[o->c0 + 3 * j], dy = y - p[o->c0 + 3 * j + 1];
         REAL h = safe2 - (dx * dx + dy * dy);
         if (h > 0) {
@@ -116,7 +129,8 @@ static void SUF(stage)(const orc_problem *pr, const SUF(offs) * o, const REAL *p
     }
     /* --- fleet collision, predictive: all Nother robots at step k, weight 10 (mpc_builder.py:93-97);
      *     c is laid out [j*3N + k*3 + f] */
-    for (int j = 0; j < pr->Nother; ++j) {
+    for (int jj = 0; jj < pr->Nother; ++jj) {
+        const int j = ORC_IDX(jj, pr->Nother);
         const REAL *cj = p + o->c + j * 3 * N + k * 3;
         REAL dx = x - cj[0], dy = y - cj[1];
         REAL h = safe2 - (dx * dx + dy * dy);
@@ -130,7 +144,8 @@ static void SUF(stage)(const orc_problem *pr, const SUF(offs) * o, const REAL *p
     /* --- static obstacles (mpc_builder.py:100-108; mpc_helper.py:54-75; mpc_cost.py:6-24) */
     {
         const REAL qs = p[o->qstc + k];
-        for (int i = 0; i < pr->Nstc; ++i) {
+        for (int ii = 0; ii < pr->Nstc; ++ii) {
+            const int i = ORC_IDX(ii, pr->Nstc);
             const REAL *b = p + o->os + 12 * i, *a0 = b + 4, *a1 = b + 8;
             REAL h[4], ind = 1;
             for (int e = 0; e < 4; ++e) {
@@ -160,11 +175,13 @@ static void SUF(stage)(const orc_problem *pr, const SUF(offs) * o, const REAL *p
 
     /* --- dynamic obstacles: snapshot t=0 (mpc_builder.py:111-125) and t=k+1 (:129-143)
      *     o_d is laid out [j*6(N+1) + t*6 + f], f = (x, y, rx, ry, angle, alpha) */
-    for (int snap = 0; snap < 2; ++snap) {
+    for (int sn = 0; sn < 2; ++sn) {
+        const int snap = ORC_IDX(sn, 2);
         const int t = snap == 0 ? 0 : k + 1;
         const REAL marg = snap == 0 ? vm + sm : vm;
         const REAL wgt = snap == 0 ? (REAL)1000 : p[o->qdyn + k];
-        for (int j = 0; j < pr->Ndyn; ++j) {
+        for (int jj = 0; jj < pr->Ndyn; ++jj) {
+            const int j = ORC_IDX(jj, pr->Ndyn);
             const REAL *e = p + o->od + j * 6 * (N + 1) + t * 6;
             REAL dx = x - e[0], dy = y - e[1];
             REAL ca = SUF(rcos)(e[4]), sa = SUF(rsin)(e[4]);
@@ -229,6 +246,9 @@ static void SUF(core)(const orc_problem *pr, const REAL *u, REAL c, const REAL *
     X[0] = p[o.s0];
     Y[0] = p[o.s0 + 1];
     TH[0] = p[o.s0 + 2];
+#ifdef ORC_REASSOC
+    REAL sumx = 0, sumy = 0, sumt = 0;
+#endif
     for (int k = 0; k < N; ++k) {
         const REAL v = u[2 * k], w = u[2 * k + 1];
         /* unicycle RK4 in closed form (ref: basic_motion_model/motion_model.py:141-163):
@@ -240,9 +260,18 @@ static void SUF(core)(const orc_problem *pr, const REAL *u, REAL c, const REAL *
         Sk[k] = (s0 + (REAL)4 * s1 + s2) / (REAL)6;
         dCw[k] = -ts * ((REAL)2 * s1 + s2) / (REAL)6;
         dSw[k] = ts * ((REAL)2 * c1 + c2) / (REAL)6;
+#ifdef ORC_REASSOC
+        sumx += ts * v * Ck[k];
+        sumy += ts * v * Sk[k];
+        sumt += ts * w;
+        X[k + 1] = X[0] + sumx;
+        Y[k + 1] = Y[0] + sumy;
+        TH[k + 1] = TH[0] + sumt;
+#else
         X[k + 1] = X[k] + ts * v * Ck[k];
         Y[k + 1] = Y[k] + ts * v * Sk[k];
         TH[k + 1] = th + ts * w;
+#endif
 
         SUF(stage)(pr, &o, p, k, X[k + 1], Y[k + 1], &f, &pen_s, F2, 0, 0, 0, 0);
         f += qvel * (v - p[o.rv + k]) * (v - p[o.rv + k]); /* mpc_cost.py:78-79 */
@@ -276,7 +305,8 @@ static void SUF(core)(const orc_problem *pr, const REAL *u, REAL c, const REAL *
     REAL dC[ORC_MAXNV]; /* z - Proj_C(z), z = F1 + y/max(c,1) */
     REAL psi = f, d2 = 0, f2s = 0;
     const REAL cdiv = c > (REAL)1 ? c : (REAL)1;
-    for (int i = 0; i < 2 * N; ++i) {
+    for (int ii = 0; ii < 2 * N; ++ii) {
+        const int i = ORC_IDX(ii, 2 * N);
         REAL lo = i < N ? (REAL)pr->lin_acc_min : (REAL)(-pr->ang_acc_max);
         REAL hi = i < N ? (REAL)pr->lin_acc_max : (REAL)pr->ang_acc_max;
         REAL z = F1[i] + (ymul ? ymul[i] : (REAL)0) / cdiv;
@@ -284,14 +314,15 @@ static void SUF(core)(const orc_problem *pr, const REAL *u, REAL c, const REAL *
         dC[i] = z - pz;
         d2 += dC[i] * dC[i];
     }
-    for (int j = 0; j < Nd; ++j) f2s += F2[j] * F2[j];
+    for (int j = 0; j < Nd; ++j) f2s += F2[ORC_IDX(j, Nd)] * F2[ORC_IDX(j, Nd)];
     psi += c * (d2 + f2s) / (REAL)2;
     if (psi_out) *psi_out = psi;
     if (!grad) return;
 
     /* ---- backward sweep: lambda = dJ/ds_{k+1}; g_k = dl/du_k + B_k^T lambda; lambda <- A_k^T lambda */
     REAL W[ORC_MAXDYN], Wsum = 0;
-    for (int j = 0; j < Nd; ++j) {
+    for (int jj = 0; jj < Nd; ++jj) {
+        const int j = ORC_IDX(jj, Nd);
         W[j] = c * F2[j];
         Wsum += W[j];
     }
@@ -343,7 +374,26 @@ typedef struct {
     REAL c;
     const REAL *y;
     int n_cost, n_grad;
+    /* optional iteration trace (orc_solve_trace_*): one record of ORC_TRACE_HEAD + n doubles per completed inner
+     * iteration -- see nmpc_oracle.h */
+    double *trace;
+    int max_rec, n_rec, outer;
+    /* scratch of the iteration in progress */
+    int t_lip, t_nls, t_cbfgs, t_kind;
+    double t_margin;
 } SUF(ctx);
+
+/* smallest relative margin of the discrete decisions taken in the iteration in progress, and which one it was
+ * (1 Lipschitz backtracking test, 2 line-search test, 3 C-BFGS / s'y acceptance, 4 exit test) */
+static void SUF(note_margin)(SUF(ctx) * cx, double m, int kind)
+{
+    if (!cx->trace) return;
+    if (m < 0) m = -m;
+    if (cx->t_kind == 0 || m < cx->t_margin) {
+        cx->t_margin = m;
+        cx->t_kind = kind;
+    }
+}
 
 static REAL SUF(cost)(SUF(ctx) * cx, const REAL *u)
 {
@@ -361,7 +411,7 @@ static void SUF(gradf)(SUF(ctx) * cx, const REAL *u, REAL *g)
 static REAL SUF(dot)(const REAL *a, const REAL *b, int n)
 {
     REAL s = 0;
-    for (int i = 0; i < n; ++i) s += a[i] * b[i];
+    for (int i = 0; i < n; ++i) s += a[ORC_IDX(i, n)] * b[ORC_IDX(i, n)];
     return s;
 }
 static REAL SUF(norm2)(const REAL *a, int n) { return SUF(rsqrt)(SUF(dot)(a, a, n)); }
@@ -392,8 +442,11 @@ static void SUF(lbfgs_reset)(SUF(lbfgs) * L)
 }
 
 /* OpEn: Lbfgs::update_hessian(g, state) incl. new_s_and_y_valid (C-BFGS test of Li & Fukushima) */
-static void SUF(lbfgs_update)(SUF(lbfgs) * L, const orc_options *op, const REAL *g, const REAL *state)
+static void SUF(lbfgs_update)(SUF(lbfgs) * L, const orc_options *op, const REAL *g, const REAL *state, int *flag,
+                              double *margin)
 {
+    *flag = -1; /* -1: first call / nothing tested, 0: pair rejected, 1: pair accepted */
+    *margin = 1e300;
     const int n = L->n, m = L->mem;
     if (L->first_old) {
         L->first_old = 0;
@@ -410,13 +463,17 @@ static void SUF(lbfgs_update)(SUF(lbfgs) * L, const orc_options *op, const REAL 
     }
     REAL ys = SUF(dot)(sn, yn, n), ss = SUF(dot)(sn, sn, n);
     int ok = 1;
+    if (op->sy_eps > 0) *margin = ((double)ys - op->sy_eps) / ((double)(ys < 0 ? -ys : ys) + 1e-300);
     if (ss <= (REAL)REAL_MIN_POS || (op->sy_eps > 0 && ys <= (REAL)op->sy_eps)) {
         ok = 0;
     } else if (op->cbfgs_eps > 0 && op->cbfgs_alpha > 0) {
         REAL lhs = ys / ss;
         REAL rhs = (REAL)op->cbfgs_eps * SUF(rpow)(SUF(norm2)(g, n), (REAL)op->cbfgs_alpha);
         ok = (lhs > rhs) && SUF(risfinite)(lhs) && SUF(risfinite)(rhs);
+        double m2 = ((double)lhs - (double)rhs) / ((double)(lhs < 0 ? -lhs : lhs) + 1e-300);
+        if ((m2 < 0 ? -m2 : m2) < (*margin < 0 ? -*margin : *margin)) *margin = m2;
     }
+    *flag = ok;
     if (!ok) return; /* rejection: old point kept */
     for (int i = 0; i < n; ++i) {
         L->old_state[i] = state[i];
@@ -542,13 +599,22 @@ static int SUF(panoc_step)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u)
      * zero after the first iteration and the source form reduces to ||gamma*fpr||. */
     {
         REAL r = 0;
-        for (int i = 0; i < n; ++i) {
+        for (int ii = 0; ii < n; ++ii) {
+            const int i = ORC_IDX(ii, n);
             REAL t = pc->gfpr[i] + pc->gamma * (pc->grad[i] - pc->grad_prev[i]);
             r += t * t;
         }
         r = SUF(rsqrt)(r);
         if (cx->op->akkt_form) r /= pc->gamma; /* documented form */
         if (pc->norm_gfpr < pc->tol && r < pc->akkt_tol) return 0;
+        cx->t_kind = 0;
+        cx->t_lip = cx->t_nls = 0;
+        cx->t_cbfgs = -1;
+        {   /* the exit test said "continue": by how much (the test that binds: the larger of the two ratios) */
+            double m1 = ((double)pc->norm_gfpr - (double)pc->tol) / (double)pc->tol;
+            double m2 = ((double)r - (double)pc->akkt_tol) / (double)pc->akkt_tol;
+            SUF(note_margin)(cx, m1 > m2 ? m1 : m2, 4);
+        }
     }
     /* update_lipschitz_constant */
     {
@@ -559,6 +625,7 @@ static int SUF(panoc_step)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u)
             REAL ip = SUF(dot)(pc->grad, pc->gfpr, n);
             REAL rhs = pc->cost_value + LIP_UPDATE_EPS * SUF(rabs)(pc->cost_value) - ip +
                        (GAMMA_L_COEFF / ((REAL)2 * pc->gamma)) * (pc->norm_gfpr * pc->norm_gfpr);
+            SUF(note_margin)(cx, ((double)cost_half - (double)rhs) / ((double)SUF(rabs)(pc->cost_value) + 1e-300), 1);
             if (!(cost_half > rhs && it < MAX_LIP_ITERS && pc->L < MAX_L)) break;
             SUF(lbfgs_reset)(&pc->lb);
             pc->L *= (REAL)2;
@@ -570,10 +637,15 @@ static int SUF(panoc_step)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u)
             pc->norm_gfpr = SUF(norm2)(pc->gfpr, n);
             ++it;
         }
+        cx->t_lip = it;
         pc->sigma = ((REAL)1 - GAMMA_L_COEFF) / ((REAL)4 * pc->gamma);
     }
     /* lbfgs_direction */
-    SUF(lbfgs_update)(&pc->lb, cx->op, pc->gfpr, u);
+    {
+        double mg;
+        SUF(lbfgs_update)(&pc->lb, cx->op, pc->gfpr, u, &cx->t_cbfgs, &mg);
+        if (cx->t_cbfgs >= 0) SUF(note_margin)(cx, mg, 3);
+    }
     if (pc->iteration > 0) {
         for (int i = 0; i < n; ++i) pc->dir[i] = pc->gfpr[i];
         SUF(lbfgs_apply)(&pc->lb, pc->dir);
@@ -588,7 +660,8 @@ static int SUF(panoc_step)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u)
     } else {
         /* linesearch: compute_rhs_ls */
         REAL dist2 = 0;
-        for (int i = 0; i < n; ++i) {
+        for (int ii = 0; ii < n; ++ii) {
+            const int i = ORC_IDX(ii, n);
             REAL t = pc->gstep[i] - pc->u_half[i];
             dist2 += t * t;
         }
@@ -606,18 +679,42 @@ static int SUF(panoc_step)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u)
             SUF(gradient_step)(pc, pc->u_plus, n);
             SUF(half_step)(cx, pc);
             REAL d2 = 0;
-            for (int i = 0; i < n; ++i) {
+            for (int ii = 0; ii < n; ++ii) {
+                const int i = ORC_IDX(ii, n);
                 REAL t = pc->gstep[i] - pc->u_half[i];
                 d2 += t * t;
             }
             pc->lhs_ls = pc->cost_value - (REAL)0.5 * pc->gamma * SUF(dot)(pc->grad, pc->grad, n) +
                          (REAL)0.5 * d2 / pc->gamma;
+            SUF(note_margin)(cx, ((double)pc->lhs_ls - (double)pc->rhs_ls) / ((double)SUF(rabs)(pc->rhs_ls) + 1e-300), 2);
             if (!(pc->lhs_ls > pc->rhs_ls && nls < MAX_LS_ITERS)) break;
             pc->tau /= (REAL)2;
             ++nls;
         }
+        cx->t_nls = nls;
         /* (OpEn sets tau = 0 / u <- u_half when nls == MAX but then overwrites u with u_plus) */
         for (int i = 0; i < n; ++i) u[i] = pc->u_plus[i];
+    }
+    if (cx->trace && cx->n_rec < cx->max_rec) {
+        double *t = cx->trace + (size_t)cx->n_rec * (ORC_TRACE_HEAD + n);
+        t[0] = cx->outer;
+        t[1] = pc->iteration;            /* index of the iteration just completed, within its outer iteration */
+        t[2] = cx->t_lip;                /* Lipschitz doublings (gamma halvings) */
+        t[3] = cx->t_nls;                /* line-search halvings of tau (0 on iteration 0: no line search) */
+        t[4] = cx->t_cbfgs;              /* -1 nothing tested, 0 pair rejected, 1 pair accepted */
+        t[5] = pc->lb.active;
+        t[6] = (double)pc->gamma;
+        t[7] = (double)pc->norm_gfpr;    /* ||gamma * fpr|| at the head of this iteration */
+        t[8] = (double)pc->cost_value;   /* psi at the new iterate */
+        t[9] = pc->iteration == 0 ? 0.0 : (double)pc->tau;
+        t[10] = cx->n_cost;
+        t[11] = cx->n_grad;
+        t[12] = cx->t_margin;            /* smallest relative margin of this iteration's decisions ... */
+        t[13] = cx->t_kind;              /* ... and which decision it was (see note_margin) */
+        t[14] = (double)cx->c;
+        t[15] = 0;
+        for (int i = 0; i < n; ++i) t[ORC_TRACE_HEAD + i] = (double)u[i];
+        cx->n_rec++;
     }
     pc->iteration++;
     return 1;
@@ -643,7 +740,8 @@ static int SUF(panoc_solve)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u, int max_it
 }
 
 /* OpEn: alm::AlmOptimizer::solve / step */
-int SUF(orc_solve)(const orc_problem *pr, const orc_options *op, const REAL *p, REAL *u, REAL *y, orc_result *res)
+static int SUF(orc_solve_impl)(const orc_problem *pr, const orc_options *op, const REAL *p, REAL *u, REAL *y,
+                               orc_result *res, double *trace, int max_rec, int *n_rec)
 {
     if (pr->N > ORC_MAXN || pr->Ndyn > ORC_MAXDYN || op->lbfgs_mem > ORC_MAX_MEM) return -1;
     const int N = pr->N, n = 2 * N, n1 = 2 * N, n2 = pr->Ndyn;
@@ -654,7 +752,7 @@ int SUF(orc_solve)(const orc_problem *pr, const orc_options *op, const REAL *p, 
     pc->lb.gamma = 1;
     pc->tol = (REAL)op->tolerance;
     pc->akkt_tol = (REAL)op->initial_tolerance;
-    SUF(ctx) cx = {pr, op, p, n, (REAL)op->initial_penalty, y, 0, 0};
+    SUF(ctx) cx = {pr, op, p, n, (REAL)op->initial_penalty, y, 0, 0, trace, max_rec, 0, 0, 0, 0, -1, 0, 0.0};
 
     REAL y_plus[ORC_MAXNV], F1[ORC_MAXNV], F2[ORC_MAXDYN];
     REAL dyn = 0, dyn_plus = 0, f2n = 0, f2n_plus = 0, last_fpr = 0;
@@ -669,6 +767,7 @@ int SUF(orc_solve)(const orc_problem *pr, const orc_options *op, const REAL *p, 
             break;
         }
         outer++;
+        cx.outer = outer;
         /* project y on Y = [-1e12, 1e12]^n1 */
         for (int i = 0; i < n1; ++i) y[i] = SUF(rmin)(SUF(rmax)(y[i], (REAL)-1e12), (REAL)1e12);
         int inner_iters;
@@ -689,7 +788,10 @@ int SUF(orc_solve)(const orc_problem *pr, const orc_options *op, const REAL *p, 
         f2n_plus = SUF(norm2)(F2, n2);
         {
             REAL s = 0;
-            for (int i = 0; i < n1; ++i) s += (y_plus[i] - y[i]) * (y_plus[i] - y[i]);
+            for (int ii = 0; ii < n1; ++ii) {
+                const int i = ORC_IDX(ii, n1);
+                s += (y_plus[i] - y[i]) * (y_plus[i] - y[i]);
+            }
             dyn_plus = SUF(rsqrt)(s);
         }
         /* is_exit_criterion_satisfied */
@@ -728,8 +830,20 @@ int SUF(orc_solve)(const orc_problem *pr, const orc_options *op, const REAL *p, 
         res->f2_norm = (double)f2n_plus;
         res->penalty = (double)cx.c;
     }
+    if (n_rec) *n_rec = cx.n_rec;
     free(pc);
     return 0;
+}
+
+int SUF(orc_solve)(const orc_problem *pr, const orc_options *op, const REAL *p, REAL *u, REAL *y, orc_result *res)
+{
+    return SUF(orc_solve_impl)(pr, op, p, u, y, res, 0, 0, 0);
+}
+
+int SUF(orc_solve_trace)(const orc_problem *pr, const orc_options *op, const REAL *p, REAL *u, REAL *y, orc_result *res,
+                         double *trace, int max_rec, int *n_rec)
+{
+    return SUF(orc_solve_impl)(pr, op, p, u, y, res, trace, max_rec, n_rec);
 }
 
 int SUF(orc_solve_batch)(const orc_problem *pr, const orc_options *op, const REAL *P, int B, REAL *U, orc_result *res,
@@ -762,3 +876,4 @@ int SUF(orc_solve_batch)(const orc_problem *pr, const orc_options *op, const REA
 #undef MAX_L
 #undef MAX_LIP_ITERS
 #undef MAX_LS_ITERS
+#undef ORC_IDX

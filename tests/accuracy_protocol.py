@@ -14,6 +14,24 @@ three comparisons each:
                                instances polished on both sides -- the headline dtype with fp64-grade answers
   ``hip32polish_vs_hip64_tight``  ... against the fp64 solve from scratch at tolerance 1e-8 (the fixed point)
   ``hip64_vs_hip64_tight``     what the DEFAULT tolerance alone pins: fp64 at 1e-4 against fp64 at 1e-8
+  ``oracle64_vs_reassociated`` THE ORACLE'S OWN NOISE FLOOR: the fp64 oracle against the same oracle with its sums
+                               associated differently (oracle/nmpc_oracle_impl.h, ORC_REASSOC: reverse accumulation order,
+                               rollout as X0 + running sum -- no rule, constant or tie-break differs), same instances, same
+                               options. Two correct fp64 implementations of this solver scatter a share of the converged
+                               instances by far more than 1e-4; ``hip64_vs_oracle64`` has to be read against that share
+  ``divergence_audit``         the first-divergence audit (below) of every pair that ends > 1e-4 apart
+
+First-divergence audit. Both sides record one line per inner iteration -- outer / inner index,
+Lipschitz doublings, line-search halvings, what became of the L-BFGS pair, gamma, ||gamma fpr||, psi, and the iterate --
+the HIP side through ``nmpc_solve_trace_f64`` (the one-wavefront fp64 kernel), the oracle through ``orc_solve_trace_*``,
+which also notes the smallest relative margin of the iteration's discrete decisions. What the traces show (and what
+``audit_pair`` asserts per pair): the two sides start together (1e-12: the Lipschitz estimate is a finite difference),
+the distance grows GRADUALLY over tens of iterations -- the L-BFGS / line-search dynamics on this non-convex problem
+amplify a rounding-level difference by a modest factor per iteration -- and only once it has reached the size of the
+decision margins do discrete decisions (a doubling more, a halving more) differ and the paths part for good. A genuine
+algorithmic difference looks different: a discrete decision that differs while the iterates still agree to rounding,
+with a margin far above their distance, or a jump of many orders of magnitude within one iteration.
+
 Used by ``tests/test_gpu_accuracy.py`` (asserts) and by ``bench.py`` (reports the table in its JSON line). Imports the
 oracle, so it lives under ``tests/``; the product package never imports it.
 """
@@ -51,6 +69,80 @@ def _stats_mask(Ua, Ub, mask):
             "max_abs_du": float(du.max()), "frac_lt_1e-4": float(np.mean(du < 1e-4))}
 
 
+# ---- first-divergence audit -------------------------------------------------------------------------------------
+DISCRETE_FIELDS = (0, 1, 2, 3, 4)   # outer, inner index, Lipschitz doublings, line-search halvings, L-BFGS pair
+START_TOL = 1e-8        # distance of the iterates over the first records (same algorithm, same start)
+JUMP_LIMIT = 1e6        # growth of the distance within ONE iteration, from a level above rounding
+MARGIN_FACTOR = 1e4     # a differing decision is a tie-break if its relative margin <= MARGIN_FACTOR * distance before it
+
+
+def audit_pair(head_a, U_a, head_b, U_b) -> dict:
+    """Lay two iteration traces of the same instance side by side. `head_b` may carry decision margins (column 12, the
+    oracle's); `head_a` need not. Returns where and how the two part, and `explained`: True when the record shows
+    rounding-level agreement at the start, gradual growth, and -- if a discrete decision differs while the iterates are
+    still closer than 1e-6 -- a margin of that decision no larger than MARGIN_FACTOR times the distance already there."""
+    n = min(len(head_a), len(head_b))
+    if n == 0:
+        return {"records": 0, "explained": True, "kind": "no inner iteration on either side"}
+    scale = max(1.0, float(np.abs(U_b[:n]).max()))
+    d = np.abs(U_a[:n] - U_b[:n]).max(axis=1) / scale
+    disc = np.any(head_a[:n][:, DISCRETE_FIELDS] != head_b[:n][:, DISCRETE_FIELDS], axis=1)
+    k_disc = int(np.argmax(disc)) if disc.any() else -1
+    k_far = int(np.argmax(d > 1e-6)) if (d > 1e-6).any() else -1
+    start = float(d[:min(3, n)].max())
+    upto = n if k_disc < 0 else k_disc + 1          # growth is judged up to the first differing decision
+    floor = 1e-13
+    jumps = d[1:upto] / np.maximum(d[:upto - 1], floor)
+    max_jump = float(jumps.max()) if jumps.size else 1.0
+    out = {"records": int(n), "start_distance": start, "first_discrete_difference": k_disc, "first_distance_gt_1e-6": k_far,
+           "max_growth_per_iteration": max_jump}
+    ok = start <= START_TOL and max_jump <= JUMP_LIMIT
+    if k_disc >= 0:
+        before = float(d[k_disc - 1]) if k_disc > 0 else 0.0
+        margin = float(min(abs(head_b[k_disc, 12]), abs(head_b[max(k_disc - 1, 0), 12]))) if head_b.shape[1] > 12 else None
+        fields = ("outer", "inner", "lipschitz_doublings", "linesearch_halvings", "lbfgs_pair")
+        which = [fields[j] for j, f in enumerate(DISCRETE_FIELDS) if head_a[k_disc, f] != head_b[k_disc, f]]
+        out.update({"distance_before_it": before, "decision_margin": margin, "differing": which})
+        if before < 1e-6:      # the iterates still agreed: the decision itself must have been a near-tie
+            ok = ok and margin is not None and margin <= MARGIN_FACTOR * max(before, 1e-12)
+        out["kind"] = "discrete decision after gradual growth" if before >= 1e-6 else "near-tie decision"
+    else:
+        out["kind"] = "gradual growth, no differing decision" if k_far >= 0 else "agree throughout"
+    out["explained"] = bool(ok)
+    return out
+
+
+def divergence_audit(nm, oracle, pr, cfg, P, pairs, opts, reassoc_pairs=()) -> dict:
+    """Audit of the instances `pairs` (HIP one-wavefront fp64 kernel vs oracle) and `reassoc_pairs` (oracle vs its
+    re-associated twin: what the same audit says about two CPU implementations)."""
+    rows, rows_r = [], []
+    with nm.Handle(cfg) as h:
+        for i in pairs:
+            t = h.solve_trace(P[i])
+            _, _, _, ho, Uo = oracle.solve_trace(pr, opts, P[i])
+            r = audit_pair(t["head"], t["Ut"], ho, Uo)
+            r["instance"] = int(i)
+            rows.append(r)
+    for i in reassoc_pairs:
+        _, _, _, ha, Ua = oracle.solve_trace(pr, opts, P[i], reassoc=True)
+        _, _, _, ho, Uo = oracle.solve_trace(pr, opts, P[i])
+        r = audit_pair(ha, Ua, ho, Uo)
+        r["instance"] = int(i)
+        rows_r.append(r)
+
+    def digest(rs):
+        return {"n_pairs": len(rs), "n_explained": sum(r["explained"] for r in rs),
+                "n_unexplained": sum(not r["explained"] for r in rs),
+                "n_tie": sum(r.get("kind") == "near-tie decision" for r in rs),
+                "median_first_discrete_difference": float(np.median([r["first_discrete_difference"] for r in rs])) if rs else None,
+                "max_growth_per_iteration": max([r["max_growth_per_iteration"] for r in rs], default=None),
+                "max_start_distance": max([r["start_distance"] for r in rs], default=None)}
+    out = digest(rows)
+    out["pairs"] = rows
+    out["oracle_vs_reassociated"] = dict(digest(rows_r), pairs=rows_r)
+    return out
+
+
 def config_for_layout(nm, layout, n_active, **overrides):
     cfg = nm.default_config_struct()
     cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs = layout.N, layout.Nother, layout.Nstc, layout.Ndyn
@@ -63,7 +155,7 @@ def config_for_layout(nm, layout, n_active, **overrides):
 
 
 def run_case(nm, oracle, workload: str, family: str, n: int | None = None, seed: int = 1234, nthreads: int = 8,
-             tight: bool = True, akkt_form: int = 0) -> dict:
+             tight: bool = True, akkt_form: int = 0, audit: bool = False, audit_max: int = 24) -> dict:
     """One (configuration, family) row of the table."""
     key, n_default = WORKLOADS[workload]
     spec = dict(nm.scenarios.BENCH_CONFIGS[key])
@@ -86,6 +178,20 @@ def run_case(nm, oracle, workload: str, family: str, n: int | None = None, seed:
     r64 = hip(np.float64)
     r32 = hip(np.float32)
     row["hip64_vs_oracle64"] = _stats(r64["U"], r64["status"], Uo, ro["status"])
+    # the oracle's own noise floor under re-association, same instances, same options
+    Ur, rr = oracle.solve_batch(pr, oracle.Options(lip_delta=LIP_STEP, lip_eps=LIP_STEP, akkt_form=akkt_form), P,
+                                nthreads=nthreads, reassoc=True)
+    row["oracle64_vs_reassociated"] = _stats(Ur, rr["status"], Uo, ro["status"])
+    if audit:
+        # first-divergence audit: the one-wavefront fp64 kernel (what nmpc_solve_trace_f64 traces) against the oracle, every
+        # instance that ends > 1e-4 apart or with another status; and the oracle against its twin, likewise
+        tp = dict(latency_waves=1, coop_waves=1, reg_table=-1)
+        rtp = hip(np.float64, **tp)
+        row["hip64tp_vs_oracle64"] = _stats(rtp["U"], rtp["status"], Uo, ro["status"])
+        far = lambda Ua, sa: np.nonzero((np.abs(Ua - Uo).max(axis=1) > 1e-4) | (sa != ro["status"]))[0][:audit_max]
+        row["divergence_audit"] = divergence_audit(
+            nm, oracle, pr, config_for_layout(nm, layout, n_active, akkt_form=akkt_form, **tp), P, far(rtp["U"], rtp["status"]),
+            oracle.Options(lip_delta=LIP_STEP, lip_eps=LIP_STEP, akkt_form=akkt_form), far(Ur, rr["status"]))
     row["hip32_vs_hip64"] = _stats(r32["U"], r32["status"], r64["U"], r64["status"])
     row["converged_frac"] = {"oracle64": float(np.mean(ro["status"] == 0)), "hip64": float(np.mean(r64["status"] == 0)),
                              "hip32": float(np.mean(r32["status"] == 0))}

@@ -27,10 +27,28 @@ pytestmark = pytest.mark.gpu
                                                ("cfg2", "toward_robot", 32), ("cfg2", "passing", 48),
                                                ("cfg4", "passing", 12)])
 def test_accuracy_protocol(workload, family, n):
-    row = run_case(nm, oracle, workload, family, n=n, nthreads=8, tight=(family == "passing"))
+    row = run_case(nm, oracle, workload, family, n=n, nthreads=8, tight=(family == "passing"),
+                   audit=(family == "passing"), audit_max=24 if workload != "cfg4" else 4)
     print(json.dumps(row))
     a, f = row["hip64_vs_oracle64"], row["hip32_vs_hip64"]
     assert a["same_status_frac"] >= 0.9, a
+    # Read against the oracle's own noise floor (the fp64 oracle vs the same oracle with its sums associated differently,
+    # same instances): the HIP kernels are statistically no further from the oracle than the oracle is from its twin.
+    fl = row["oracle64_vs_reassociated"]
+    assert a["same_status_frac"] >= fl["same_status_frac"] - 0.1, (a, fl)
+    if fl["both_converged"] and a["both_converged"]:
+        assert a["frac_lt_1e-4_both_converged"] >= fl["frac_lt_1e-4_both_converged"] - 0.2, (a, fl)
+    if family == "passing":
+        # first-divergence audit: every pair that ends > 1e-4 apart (one-wavefront fp64 kernel vs oracle) starts together,
+        # drifts apart gradually and shows its first differing decision only after that -- or at a near-tie; exactly what
+        # the two CPU implementations do among themselves. A genuine algorithmic difference would fail here.
+        au = row["divergence_audit"]
+        print("audit:", {k: v for k, v in au.items() if k not in ("pairs", "oracle_vs_reassociated")},
+              "| oracle vs twin:", {k: v for k, v in au["oracle_vs_reassociated"].items() if k != "pairs"})
+        assert au["n_unexplained"] == 0, [p for p in au["pairs"] if not p["explained"]]
+        assert au["oracle_vs_reassociated"]["n_unexplained"] == 0
+        t = row["hip64tp_vs_oracle64"]
+        assert t["same_status_frac"] >= fl["same_status_frac"] - 0.1, (t, fl)
     if family == "passing":                    # the family where the solver converges
         t = row["hip64_vs_oracle64_tight"]
         assert t["same_status_frac"] >= 0.75, t
@@ -96,3 +114,31 @@ def test_tight_solutions_match_an_independent_nlp_solver():
             #  stop wherever 12 x 3000 iterations took them: within ~1e-2)
             assert conv.sum() >= 9 and du[conv].max() < bound and np.median(du) < med, (dtype, name, du)
             assert dtype == np.float32 or du.max() < 2e-2, (dtype, name, du)   # (fp32: such an instance is flagged, not pinned)
+
+
+def test_trace_kernel_is_the_batch_solver_and_starts_on_the_oracles_path():
+    """nmpc_solve_trace_f64 = the one-wavefront fp64 kernel of nmpc_solve_batch_f64 (latency_waves = 1, LDS table), bit for
+    bit, plus one record per inner iteration; over the first iterations its records coincide with the oracle's trace
+    (same discrete decisions, iterates to 1e-9)."""
+    from accuracy_protocol import LIP_STEP, config_for_layout
+    lay = nm.scenarios.ParamLayout()
+    P = nm.scenarios.make_batch(12, lay, seed=1234, n_ped=2, n_hyp=5, ped_mode="passing")
+    pr = oracle.Problem()
+    cfg = config_for_layout(nm, lay, 10, latency_waves=1, coop_waves=1, reg_table=-1)
+    op = oracle.Options(lip_delta=LIP_STEP, lip_eps=LIP_STEP)
+    with nm.Handle(cfg) as h:
+        ref = h.solve(P, dtype=np.float64)
+        for i in range(12):
+            t = h.solve_trace(P[i])
+            assert np.array_equal(t["U"], ref["U"][i]) and t["status"] == ref["status"][i]
+            assert np.array_equal(t["iters"], ref["iters"][i]) and np.array_equal(t["info"][:6], ref["info"][i][:6])
+            assert np.array_equal(t["Ut"][-1], t["head"][-1, 16:]) if t["head"].shape[1] > 16 else True
+            _, _, res, ho, Uo = oracle.solve_trace(pr, op, P[i])
+            k = min(8, len(ho), len(t["head"]))
+            assert np.array_equal(t["head"][:k, :5], ho[:k, :5]), (i, t["head"][:k, :5], ho[:k, :5])
+            assert np.abs(t["Ut"][:k] - Uo[:k]).max() < 1e-9
+            assert np.allclose(t["head"][:k, 6], ho[:k, 6], rtol=1e-8) and np.allclose(t["head"][:k, 7], ho[:k, 7], rtol=1e-6, atol=1e-12)
+        # a continuation from a given state: u0 / y0 / c0 go through as in the batch entry point
+        t0 = h.solve_trace(P[0], u0=ref["U"][0], y0=ref["y"][0], c0=float(ref["info"][0, 3]))
+        r0 = h.solve(P[:1], u0=ref["U"][:1], y0=ref["y"][:1], c0=ref["info"][:1, 3].copy(), dtype=np.float64)
+        assert np.array_equal(t0["U"], r0["U"][0])
