@@ -36,7 +36,7 @@ def test_accuracy_protocol(workload, family, n):
     # same instances): the HIP kernels are statistically no further from the oracle than the oracle is from its twin.
     fl = row["oracle64_vs_reassociated"]
     assert a["same_status_frac"] >= fl["same_status_frac"] - 0.1, (a, fl)
-    if fl["both_converged"] and a["both_converged"]:
+    if fl["both_converged"] >= 8 and a["both_converged"] >= 8:      # (a fraction of a handful says nothing)
         assert a["frac_lt_1e-4_both_converged"] >= fl["frac_lt_1e-4_both_converged"] - 0.2, (a, fl)
     if family == "passing":
         # first-divergence audit: every pair that ends > 1e-4 apart (one-wavefront fp64 kernel vs oracle) starts together,
