@@ -512,6 +512,19 @@ __global__ __launch_bounds__(64) void selftest_kernel(int* fails)
             if (c1 != nmpc::ref_class3_sum(x) || c2 != nmpc::ref_class3_sum(T(4) - x)) bad |= 2048;
         }
     }
+    if (sizeof(T) == 4) { // sincos_medium against the library on its whole range, sign and quadrant boundaries included
+        for (int round = 0; round < 64; ++round) {
+            const int i = round * 64 + lane;
+            float x = (float)((i * 2654435761u) >> 8) * (1.0f / 16777216.0f);            // [0, 1)
+            x = (i & 3) == 0 ? x * 8.0f - 4.0f : (i & 3) == 1 ? (x - 0.5f) * 200.0f : (i & 3) == 2 ? (x - 0.5f) * 2.6e5f
+                                                                                                : 0.78539816f * (float)((i >> 2) % 17 - 8) + (x - 0.5f) * 1e-4f;
+            float s1, c1, s2, c2;
+            sincosf(x, &s1, &c1);
+            nmpc::sincos_medium(x, s2, c2);
+            if (__builtin_bit_cast(unsigned, s1) != __builtin_bit_cast(unsigned, s2) ||
+                __builtin_bit_cast(unsigned, c1) != __builtin_bit_cast(unsigned, c2)) bad |= 4096;
+        }
+    }
     if (bad) atomicOr(fails, bad);
 }
 
@@ -1074,7 +1087,7 @@ int polish_batch(nmpc_handle_s* h, const nmpc::KParams<T>& k, int B, bool y_user
     q.max_inner = c.polish_max_inner_iterations;
     if (c.polish == 1) {
         // ONE inner solve at the penalty and multipliers the main solve ended with (KParams::single_inner): what the
-        // continuation needs is stationarity to polish_tolerance; the feasibility criteria stay at the main solve's delta.
+        // continuation needs is stationarity to polish_tolerance; the hard-constraint criterion stays at the main solve's delta.
         // Measured (tools/exp_polish_stats.py, configs[2] `passing`): the first inner solve of the ALM continuation takes
         // 123 evaluations and leaves the controls 1.8e-5 (median) from the 1e-8 fixed point, 86.6 % below 1e-4; the outer
         // iterations behind it -- the second one is mandatory in OpEn's loop -- add 131 evaluations for 1.1e-5 / 86.9 %.

@@ -413,7 +413,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             dyn_plus = tsqrt(I.dot2(e1, e2, e1, e2));
             const T SMALL = Lim<T>::eps;
             const int single = kc->single_inner; // (polish: see KParams::single_inner; `status` = how the inner solve ended)
-            const bool c1 = (alm_iter > 0 || single) && dyn_plus <= c * kc->delta_tol + SMALL;
+            const bool c1 = single || (alm_iter > 0 && dyn_plus <= c * kc->delta_tol + SMALL); // (single: y is not updated)
             const bool c2 = n2 == 0 || f2n_plus <= kc->delta_tol + SMALL;
             const bool c3 = akkt_tol <= kc->tol + SMALL;
             bool finished = false, converged = false, out_of_time = false;

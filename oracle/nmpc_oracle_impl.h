@@ -380,7 +380,7 @@ typedef struct {
     int max_rec, n_rec, outer;
     /* scratch of the iteration in progress */
     int t_lip, t_nls, t_cbfgs, t_kind;
-    double t_margin;
+    double t_margin, t_steep;
 } SUF(ctx);
 
 /* smallest relative margin of the discrete decisions taken in the iteration in progress, and which one it was
@@ -610,6 +610,7 @@ static int SUF(panoc_step)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u)
         cx->t_kind = 0;
         cx->t_lip = cx->t_nls = 0;
         cx->t_cbfgs = -1;
+        if (cx->trace) cx->t_steep = (double)SUF(norm2)(pc->grad, n) / ((double)SUF(rabs)(pc->cost_value) + 1e-300);
         {   /* the exit test said "continue": by how much (the test that binds: the larger of the two ratios) */
             double m1 = ((double)pc->norm_gfpr - (double)pc->tol) / (double)pc->tol;
             double m2 = ((double)r - (double)pc->akkt_tol) / (double)pc->akkt_tol;
@@ -712,7 +713,8 @@ static int SUF(panoc_step)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u)
         t[12] = cx->t_margin;            /* smallest relative margin of this iteration's decisions ... */
         t[13] = cx->t_kind;              /* ... and which decision it was (see note_margin) */
         t[14] = (double)cx->c;
-        t[15] = 0;
+        t[15] = cx->t_steep;             /* ||grad psi|| / |psi| at the head of this iteration: what a distance in u is worth
+                                            in relative psi -- at penalties of 1e6 a 1e-13 apart is a 1e-7 apart in psi */
         for (int i = 0; i < n; ++i) t[ORC_TRACE_HEAD + i] = (double)u[i];
         cx->n_rec++;
     }
@@ -752,7 +754,7 @@ static int SUF(orc_solve_impl)(const orc_problem *pr, const orc_options *op, con
     pc->lb.gamma = 1;
     pc->tol = (REAL)op->tolerance;
     pc->akkt_tol = (REAL)op->initial_tolerance;
-    SUF(ctx) cx = {pr, op, p, n, (REAL)op->initial_penalty, y, 0, 0, trace, max_rec, 0, 0, 0, 0, -1, 0, 0.0};
+    SUF(ctx) cx = {pr, op, p, n, (REAL)op->initial_penalty, y, 0, 0, trace, max_rec, 0, 0, 0, 0, -1, 0, 0.0, 0.0};
 
     REAL y_plus[ORC_MAXNV], F1[ORC_MAXNV], F2[ORC_MAXDYN];
     REAL dyn = 0, dyn_plus = 0, f2n = 0, f2n_plus = 0, last_fpr = 0;

@@ -73,7 +73,8 @@ def _stats_mask(Ua, Ub, mask):
 DISCRETE_FIELDS = (0, 1, 2, 3, 4)   # outer, inner index, Lipschitz doublings, line-search halvings, L-BFGS pair
 START_TOL = 1e-8        # distance of the iterates over the first records (same algorithm, same start)
 JUMP_LIMIT = 1e6        # growth of the distance within ONE iteration, from a level above rounding
-MARGIN_FACTOR = 1e4     # a differing decision is a tie-break if its relative margin <= MARGIN_FACTOR * distance before it
+MARGIN_FACTOR = 1e3     # a differing decision is a tie-break if its relative margin <= MARGIN_FACTOR * (distance before it,
+                        # at least 1e-13) * max(1, ||grad psi|| / |psi|) -- what that distance is worth in relative psi
 
 
 def audit_pair(head_a, U_a, head_b, U_b) -> dict:
@@ -90,7 +91,7 @@ def audit_pair(head_a, U_a, head_b, U_b) -> dict:
     k_disc = int(np.argmax(disc)) if disc.any() else -1
     k_far = int(np.argmax(d > 1e-6)) if (d > 1e-6).any() else -1
     start = float(d[:min(3, n)].max())
-    upto = n if k_disc < 0 else k_disc + 1          # growth is judged up to the first differing decision
+    upto = n if k_disc < 0 else max(k_disc, 1)      # growth is judged up to (not across) the first differing decision
     floor = 1e-13
     jumps = d[1:upto] / np.maximum(d[:upto - 1], floor)
     max_jump = float(jumps.max()) if jumps.size else 1.0
@@ -104,7 +105,9 @@ def audit_pair(head_a, U_a, head_b, U_b) -> dict:
         which = [fields[j] for j, f in enumerate(DISCRETE_FIELDS) if head_a[k_disc, f] != head_b[k_disc, f]]
         out.update({"distance_before_it": before, "decision_margin": margin, "differing": which})
         if before < 1e-6:      # the iterates still agreed: the decision itself must have been a near-tie
-            ok = ok and margin is not None and margin <= MARGIN_FACTOR * max(before, 1e-12)
+            steep = float(max(1.0, head_b[k_disc, 15], head_b[max(k_disc - 1, 0), 15])) if head_b.shape[1] > 15 else 1.0
+            out["steepness"] = steep
+            ok = ok and margin is not None and margin <= MARGIN_FACTOR * max(before, 1e-13) * steep
         out["kind"] = "discrete decision after gradual growth" if before >= 1e-6 else "near-tie decision"
     else:
         out["kind"] = "gradual growth, no differing decision" if k_far >= 0 else "agree throughout"

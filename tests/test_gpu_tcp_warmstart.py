@@ -78,3 +78,45 @@ def test_warm_started_closed_loop_is_cheaper_and_as_good():
           np.nanmean(warm.deviation[:, 0]))
     assert warm.complete.mean() >= cold.complete.mean() - 0.05
     assert sum(warm.solve_ms) < 1.25 * sum(cold.solve_ms)     # not a speed-up in general: more robots stay in the run
+
+
+def test_golden_wire_bytes_against_the_oracle():
+    """the request bytes of opengen's client (tests/golden/tcp_wire.json -- recalled, each with its
+    opengen source named) over a RAW socket to the real solver, and the answer document checked against the ORACLE (not
+    against the in-process call): controls, exit status, iteration counts, cost, and the multipliers / penalty round trip."""
+    import json
+    import os
+    import socket
+    import oracle
+    from test_tcp_cpu import _raw_bytes, _run_bytes, _wire
+    w = _wire()
+    cfg = nm.default_config_struct()
+    cfg.max_outer_iterations, cfg.max_inner_iterations = 2, 6        # (short solves: the iterate paths coincide to 1e-7)
+    cfg.lip_eps_f64 = cfg.lip_delta_f64 = 1e-4
+    opts = oracle.Options(max_outer=2, max_inner=6, lip_delta=1e-4, lip_eps=1e-4)
+    pr = oracle.Problem()
+    P = _batch(3, seed=11).astype(np.float64)
+    mng = tcp.OptimizerTcpManager(solver_factory=lambda: Solver(cfg, keep_multipliers=False))
+    mng.start()
+    try:
+        assert json.loads(_raw_bytes(mng, w["requests"]["ping"]["bytes"].encode())) == {"Pong": 1}
+        for b in range(3):
+            u0 = None if b == 0 else [0.3, 0.01] * 20
+            y0 = None if b < 2 else [0.05] * 40
+            c0 = None if b < 2 else 40.0
+            d = json.loads(_raw_bytes(mng, _run_bytes(w, P[b].tolist(), u0, y0, c0)), object_pairs_hook=list)
+            assert [k for k, _ in d] == w["responses"]["solution_fields_in_order"]
+            d = dict(d)
+            o = oracle.Options(**{**opts.__dict__, "initial_penalty": c0 or 10.0})
+            u, y, res = oracle.solve(pr, o, P[b], u0=u0, y0=y0)
+            assert d["exit_status"] == oracle.STATUS_NAMES[res["status"]]
+            assert d["num_outer_iterations"] == res["outer_iters"] and d["num_inner_iterations"] == res["inner_iters"]
+            assert np.abs(np.array(d["solution"]) - u).max() < 1e-7
+            assert abs(d["cost"] - res["cost"]) < 1e-7 * max(1.0, abs(res["cost"]))
+            assert np.abs(np.array(d["lagrange_multipliers"]) - y).max() < 1e-6 * max(1.0, np.abs(y).max())
+            assert abs(d["penalty"] - res["penalty"]) <= 1e-12 * res["penalty"] and d["solve_time_ms"] > 0
+            assert abs(d["f2_norm"] - res["f2_norm"]) < 1e-7 and abs(d["last_problem_norm_fpr"] - res["last_fpr"]) < 1e-6 * max(1e-6, res["last_fpr"])
+        e = dict(json.loads(_raw_bytes(mng, _run_bytes(w, [0.0] * 11)), object_pairs_hook=list))
+        assert e["type"] == "Error" and e["code"] == 1600
+    finally:
+        mng.kill()

@@ -233,3 +233,67 @@ def test_the_references_own_tcp_consumer_accepts_our_answers():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+# ---- the recalled wire documents as golden bytes (tests/golden/tcp_wire.json) ----------------------------------------
+def _wire():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "tcp_wire.json")))
+
+
+def _run_bytes(w, p, u0=None, y0=None, c0=None) -> bytes:
+    """the request exactly as opengen's client assembles it (string concatenation of map(str, .), NOT json.dumps)"""
+    t = w["requests"]["run_template"]
+    s = t["prefix"] + t["join"].join(map(str, p)) + "]"
+    if u0 is not None:
+        s += t["initial_guess"] + t["join"].join(map(str, u0)) + "]"
+    if y0 is not None:
+        s += t["initial_lagrange_multipliers"] + t["join"].join(map(str, y0)) + "]"
+    if c0 is not None:
+        s += t["initial_penalty"] + str(float(c0))
+    return (s + "}}").encode()
+
+
+def _raw_bytes(mng, payload: bytes) -> bytes:
+    with socket.create_connection((mng.ip, mng.port), timeout=10) as s:
+        s.sendall(payload)
+        s.shutdown(socket.SHUT_WR)
+        data = b""
+        while True:
+            c = s.recv(4096)
+            if not c:
+                break
+            data += c
+    return data
+
+
+def test_golden_wire_bytes_against_the_server(manager):
+    """The exact request bytes opengen's client writes (recalled; each with its opengen source named in the fixture) over a
+    raw socket, and the shape of what comes back: field names IN ORDER, JSON types, status strings, error documents."""
+    mng, fake = manager
+    w = _wire()
+    assert json.loads(_raw_bytes(mng, w["requests"]["ping"]["bytes"].encode())) == w["responses"]["pong"]["document"]
+    p = [0.25, 1e-05, -0.0] + [0.0] * 2775
+    req = _run_bytes(w, p, u0=[0.1] * 40, y0=[0.0] * 40, c0=25)
+    assert req.startswith(b'{"Run" : {"parameter": [0.25,1e-05,-0.0,0.0,') and req.endswith(b', "initial_penalty": 25.0}}')
+    ans = _raw_bytes(mng, req)
+    d = json.loads(ans, object_pairs_hook=list)                      # keeps the order of the fields on the wire
+    assert [k for k, _ in d] == w["responses"]["solution_fields_in_order"]
+    types = {"str": str, "int": int, "float": float}
+    for k, v in d:
+        t = w["responses"]["solution_field_types"][k]
+        if t.startswith("list"):
+            assert isinstance(v, list) and len(v) == 40 and all(isinstance(x, float) for x in v), k
+        else:
+            assert type(v) is types[t], (k, v)
+    assert dict(d)["exit_status"] in w["responses"]["exit_status_values"]
+    assert fake.calls[-1] == ([0.1] * 40, [0.0] * 40, 25.0)
+    # error documents: fields in order, the template's codes and messages
+    for code, payload in ((1600, _run_bytes(w, [0.0] * 7)), (1700, _run_bytes(w, p, u0=[0.0] * 3)),
+                          (1800, _run_bytes(w, p, y0=[0.0] * 3)), (2000, _run_bytes(w, [-999.0] + [0.0] * 2777)),
+                          (1000, b'{"Run" : {"parameter": [0.1,')):
+        e = json.loads(_raw_bytes(mng, payload), object_pairs_hook=list)
+        assert [k for k, _ in e] == w["responses"]["error_fields_in_order"]
+        e = dict(e)
+        assert e["type"] == "Error" and e["code"] == code and w["responses"]["errors"][str(code)] in e["message"], e
+    # Kill: no answer, the server is gone afterwards
+    assert _raw_bytes(mng, w["requests"]["kill"]["bytes"].encode()) == b""
