@@ -141,7 +141,7 @@ class Options:
 TRACE_HEAD = 16   # ORC_TRACE_HEAD
 TRACE_FIELDS = ("outer", "iter", "lip_doublings", "ls_halvings", "pair", "pairs_held", "gamma", "norm_gfpr", "psi", "tau",
                 "n_cost", "n_grad", "margin", "margin_kind", "penalty", "steepness")
-MARGIN_KINDS = {0: "-", 1: "lipschitz", 2: "linesearch", 3: "pair", 4: "exit"}
+MARGIN_KINDS = {0: "-", 1: "lipschitz", 2: "linesearch", 3: "pair", 4: "exit", 5: "outer loop (exit criteria / penalty stall test)"}
 
 
 def _suffix(dtype, reassoc: bool = False) -> str:

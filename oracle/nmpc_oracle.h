@@ -122,7 +122,8 @@ int orc_solve_batch_r64(const orc_problem *pr, const orc_options *op, const doub
  *   [4] L-BFGS pair: -1 not tested / 0 rejected / 1 accepted  [5] pairs in the buffer  [6] gamma  [7] ||gamma fpr||
  *   [8] psi at the new iterate  [9] tau  [10] cost evaluations so far  [11] gradient evaluations so far
  *   [12] smallest relative margin of the iteration's discrete decisions  [13] which: 1 Lipschitz test, 2 line-search
- *   test, 3 pair acceptance, 4 exit test  [14] penalty c  [15] ||grad psi|| / |psi| at the head of the iteration
+ *   test, 3 pair acceptance, 4 exit test, 5 the outer loop's tests before this inner solve (exit criteria, penalty
+ *   stall test; noted on the first record of an outer iteration)  [14] penalty c  [15] ||grad psi|| / |psi| at the head of the iteration
  *   [16..] u after the iteration */
 #define ORC_TRACE_HEAD 16
 int orc_solve_trace_f64(const orc_problem *pr, const orc_options *op, const double *p, double *u, double *y,

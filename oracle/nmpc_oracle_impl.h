@@ -381,6 +381,8 @@ typedef struct {
     /* scratch of the iteration in progress */
     int t_lip, t_nls, t_cbfgs, t_kind;
     double t_margin, t_steep;
+    double outer_margin; /* smallest relative margin of the outer loop's decisions that preceded this inner solve (kind 5) */
+    int outer_margin_set;
 } SUF(ctx);
 
 /* smallest relative margin of the discrete decisions taken in the iteration in progress, and which one it was
@@ -611,6 +613,10 @@ static int SUF(panoc_step)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u)
         cx->t_lip = cx->t_nls = 0;
         cx->t_cbfgs = -1;
         if (cx->trace) cx->t_steep = (double)SUF(norm2)(pc->grad, n) / ((double)SUF(rabs)(pc->cost_value) + 1e-300);
+        if (cx->outer_margin_set && pc->iteration == 0) { /* first iteration of an outer iteration: the ALM decisions before it */
+            SUF(note_margin)(cx, cx->outer_margin, 5);
+            cx->outer_margin_set = 0;
+        }
         {   /* the exit test said "continue": by how much (the test that binds: the larger of the two ratios) */
             double m1 = ((double)pc->norm_gfpr - (double)pc->tol) / (double)pc->tol;
             double m2 = ((double)r - (double)pc->akkt_tol) / (double)pc->akkt_tol;
@@ -754,7 +760,7 @@ static int SUF(orc_solve_impl)(const orc_problem *pr, const orc_options *op, con
     pc->lb.gamma = 1;
     pc->tol = (REAL)op->tolerance;
     pc->akkt_tol = (REAL)op->initial_tolerance;
-    SUF(ctx) cx = {pr, op, p, n, (REAL)op->initial_penalty, y, 0, 0, trace, max_rec, 0, 0, 0, 0, -1, 0, 0.0, 0.0};
+    SUF(ctx) cx = {pr, op, p, n, (REAL)op->initial_penalty, y, 0, 0, trace, max_rec, 0, 0, 0, 0, -1, 0, 0.0, 0.0, 0.0, 0};
 
     REAL y_plus[ORC_MAXNV], F1[ORC_MAXNV], F2[ORC_MAXDYN];
     REAL dyn = 0, dyn_plus = 0, f2n = 0, f2n_plus = 0, last_fpr = 0;
@@ -807,6 +813,26 @@ static int SUF(orc_solve_impl)(const orc_problem *pr, const orc_options *op, con
         /* is_penalty_stall_criterion */
         int stall = (alm_iter == 0) || ((dyn_plus <= (REAL)op->sufficient_decrease * dyn + SMALL) &&
                                         (n2 == 0 || f2n_plus <= (REAL)op->sufficient_decrease * f2n + SMALL));
+        if (trace) { /* how close the outer loop's decisions were: exit criteria 1 and 2, the two halves of the stall test */
+            double m = 1e300, t;
+            const double tiny = 1e-300;
+            if (alm_iter > 0) {
+                t = ((double)dyn_plus - (double)cx.c * op->delta_tolerance) / ((double)cx.c * op->delta_tolerance + tiny);
+                if (fabs(t) < fabs(m)) m = t;
+                t = ((double)dyn_plus - op->sufficient_decrease * (double)dyn) / ((double)dyn_plus + tiny);
+                if (fabs(t) < fabs(m)) m = t;
+                if (n2 > 0) {
+                    t = ((double)f2n_plus - op->sufficient_decrease * (double)f2n) / ((double)f2n_plus + tiny);
+                    if (fabs(t) < fabs(m)) m = t;
+                }
+            }
+            if (n2 > 0) {
+                t = ((double)f2n_plus - op->delta_tolerance) / (op->delta_tolerance + tiny);
+                if (fabs(t) < fabs(m)) m = t;
+            }
+            cx.outer_margin = m;
+            cx.outer_margin_set = 1;
+        }
         if (!stall) cx.c *= (REAL)op->penalty_update;
         /* update_inner_akkt_tolerance */
         pc->akkt_tol = SUF(rmax)(pc->akkt_tol * (REAL)op->inner_tol_update, (REAL)op->tolerance);

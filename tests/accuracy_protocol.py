@@ -70,7 +70,8 @@ def _stats_mask(Ua, Ub, mask):
 
 
 # ---- first-divergence audit -------------------------------------------------------------------------------------
-DISCRETE_FIELDS = (0, 1, 2, 3, 4)   # outer, inner index, Lipschitz doublings, line-search halvings, L-BFGS pair
+DISCRETE_FIELDS = (0, 1, 2, 3, 4, 14)   # outer, inner index, Lipschitz doublings, line-search halvings, L-BFGS pair, penalty
+                                        # (the penalty changes by the factor 5 or not at all: an outer-loop decision)
 START_TOL = 1e-8        # distance of the iterates over the first records (same algorithm, same start)
 JUMP_LIMIT = 1e6        # growth of the distance within ONE iteration, from a level above rounding
 MARGIN_FACTOR = 1e3     # a differing decision is a tie-break if its relative margin <= MARGIN_FACTOR * (distance before it,
@@ -101,9 +102,10 @@ def audit_pair(head_a, U_a, head_b, U_b) -> dict:
     if k_disc >= 0:
         before = float(d[k_disc - 1]) if k_disc > 0 else 0.0
         margin = float(min(abs(head_b[k_disc, 12]), abs(head_b[max(k_disc - 1, 0), 12]))) if head_b.shape[1] > 12 else None
-        fields = ("outer", "inner", "lipschitz_doublings", "linesearch_halvings", "lbfgs_pair")
+        fields = ("outer", "inner", "lipschitz_doublings", "linesearch_halvings", "lbfgs_pair", "penalty")
         which = [fields[j] for j, f in enumerate(DISCRETE_FIELDS) if head_a[k_disc, f] != head_b[k_disc, f]]
-        out.update({"distance_before_it": before, "decision_margin": margin, "differing": which})
+        out.update({"distance_before_it": before, "decision_margin": margin, "differing": which,
+                    "record_a": [float(x) for x in head_a[k_disc, :16]], "record_b": [float(x) for x in head_b[k_disc, :16]]})
         if before < 1e-6:      # the iterates still agreed: the decision itself must have been a near-tie
             steep = float(max(1.0, head_b[k_disc, 15], head_b[max(k_disc - 1, 0), 15])) if head_b.shape[1] > 15 else 1.0
             out["steepness"] = steep
