@@ -208,10 +208,18 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
     waves = int(info[0, 7])          # 0: throughput kernel; > 0: latency kernel with that many wavefronts per instance
     tname = "float" if dtype == "f32" else "double"
     lps = kinfo["lanes_per_step"]
-    # short name for the line (matches the rocprofv3 kernel-trace name up to the template tail); prose in bench_detail.json
-    kernel_name = (f"solve_spec_kernel<{tname},{lps}> W={waves}" if waves > 0
+    # short name for the line: the rocprofv3 kernel-trace name (register-table kernels are pairs: <.., slots, 1> = the
+    # axis-aligned member, <.., 2> = the general one); prose in bench_detail.json
+    li = nm.layout_info(cfg) if hasattr(nm, "layout_info") and not isinstance(cfg, type(None)) else None
+    try:
+        rs = int(li.reg_slots_f32) if (li is not None and dtype == "f32") else 0
+    except Exception:
+        rs = 0
+    member = {2: 1, 1: 1, 0: 2}.get(launch["axis_aligned"], 0)
+    tail = f",false,{rs},{member}" if (rs and lps == 3 and waves >= 0 and member) else ""
+    kernel_name = (f"solve_spec_kernel<{tname},{lps}{tail}> W={waves}" if waves > 0
                    else f"solve_coop_kernel<{tname},{lps}> W={-waves}" if waves < 0
-                   else f"solve_kernel<{tname},{lps}>")
+                   else f"solve_kernel<{tname},{lps}{tail}>")
     kernel_desc = ("latency mode: several wavefronts per instance, speculative line search" if waves > 0
                    else "cooperative: the wavefronts of a workgroup share each evaluation" if waves < 0
                    else "one wavefront per instance")
@@ -219,8 +227,7 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
     achieved_tf = flops_launch / (k_ms * 1e-3) / 1e12
     conv = status == 0
     if launch["axis_aligned"] == 2:
-        kernel_name += " axis"
-        kernel_desc += "; axis-aligned code path chosen on the device"
+        kernel_desc += "; axis-aligned member of the kernel pair chosen on the device (the general twin returns at once)"
     if launch["staged_outer_iterations"]:
         kernel_name += " x2 launches"
         kernel_desc += f"; two launches: pilot of {launch['staged_outer_iterations']} outer iteration(s), rest ranked by ||F2||"

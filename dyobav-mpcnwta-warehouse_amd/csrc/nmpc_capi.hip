@@ -159,7 +159,7 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false,
     L.lds_left = L.lds_alpha + (L.glb ? 0 : round4(ne));
     L.lds_left_alpha = L.lds_left + nmpc::kEllStride * left_ne;
     L.lds_poly = L.lds_left_alpha + round4(left_ne);
-    L.lds_seg = L.lds_poly + 12 * c.Nstcobs;
+    L.lds_seg = L.lds_poly + 12 * (c.Nstcobs + 3); // (+3: dummy polygons behind the stored ones, nmpc_device.h load())
     // path segments: N real ones + far-away dummies up to 2 N + 4, so that every lane can run the same number of loop trips
     // over `first segment + 3 j` without a bound (nmpc_device.h, eval(): the segment loop)
     const int nseg = nmpc::seg_table_len(N);
@@ -260,17 +260,21 @@ template <typename T, int LPS, bool GLB, int RS = 0, int ONLY = 0>
 __global__ __launch_bounds__(64, (wpe<T, RS>(NMPC_WPE_F32))) void solve_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int inst = nmpc::dispatch_index(kp);
-    if (nmpc::finished_in_pilot<T>(inst)) return;
     if constexpr (kHasAxisVariant<T, LPS, RS> && !GLB) {
         const bool axis = nmpc::axis_path(kp);
-        if (ONLY != 0 && axis != (ONLY == 1)) return;
+        if (ONLY != 0 && axis != (ONLY == 1)) return; // (a pair: the twin of the path this launch takes returns at once)
+        const int inst = nmpc::dispatch_index(kp);
+        if (nmpc::finished_in_pilot<T>(inst)) return;
         if (ONLY != 2 && axis) {
             nmpc::solve_instance<T, LPS, GLB, RS, false, false, true>(kp, inst, reinterpret_cast<T*>(smem));
             return;
         }
+        if constexpr (ONLY != 1) nmpc::solve_instance<T, LPS, GLB, RS>(kp, inst, reinterpret_cast<T*>(smem));
+    } else {
+        const int inst = nmpc::dispatch_index(kp);
+        if (nmpc::finished_in_pilot<T>(inst)) return;
+        nmpc::solve_instance<T, LPS, GLB, RS>(kp, inst, reinterpret_cast<T*>(smem));
     }
-    if constexpr (ONLY != 1) nmpc::solve_instance<T, LPS, GLB, RS>(kp, inst, reinterpret_cast<T*>(smem));
 }
 
 // diagnostic: the one-wavefront fp64 solver (LDS / global table) writing one record per inner iteration (KParams::trace)
@@ -302,19 +306,25 @@ __global__ __launch_bounds__(64 * kCoopRegWaves, 2) void solve_coop_reg_kernel(n
 }
 
 // latency mode: kSpecWaves wavefronts per instance, speculative line search (nmpc_spec.h)
-template <typename T, int LPS, bool GLB, int RS = 0>
+template <typename T, int LPS, bool GLB, int RS = 0, int ONLY = 0>
 __global__ __launch_bounds__(64 * kSpecWaves, (wpe<T, RS>(NMPC_SPEC_WPE_F32))) void solve_spec_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int inst = nmpc::dispatch_index(kp);
-    if (nmpc::finished_in_pilot<T>(inst)) return;
     if constexpr (kHasAxisVariant<T, LPS, RS> && !GLB) {
-        if (nmpc::axis_path(kp)) {
+        const bool axis = nmpc::axis_path(kp);
+        if (ONLY != 0 && axis != (ONLY == 1)) return; // (a pair: the twin of the path this launch takes returns at once)
+        const int inst = nmpc::dispatch_index(kp);
+        if (nmpc::finished_in_pilot<T>(inst)) return;
+        if (ONLY != 2 && axis) {
             nmpc::solve_instance_spec<T, LPS, GLB, RS, true>(kp, inst, reinterpret_cast<T*>(smem));
             return;
         }
+        if constexpr (ONLY != 1) nmpc::solve_instance_spec<T, LPS, GLB, RS>(kp, inst, reinterpret_cast<T*>(smem));
+    } else {
+        const int inst = nmpc::dispatch_index(kp);
+        if (nmpc::finished_in_pilot<T>(inst)) return;
+        nmpc::solve_instance_spec<T, LPS, GLB, RS>(kp, inst, reinterpret_cast<T*>(smem));
     }
-    nmpc::solve_instance_spec<T, LPS, GLB, RS>(kp, inst, reinterpret_cast<T*>(smem));
 }
 
 template <typename T, int LPS, bool GLB, int RS, bool AXIS>
@@ -654,24 +664,30 @@ void (*pick_solve_coop_reg(int N))(nmpc::KParams<float>)
 }
 
 // (the register-table variants exist for float with three lanes per step only)
+// The register-table kernels come as PAIRS since round 4 -- <.., 1> = the axis-aligned path alone, <.., 2> = the general
+// (rotated-ellipse) path alone, launched one behind the other, each workgroup of the twin that the device-side flag does
+// not pick returning before it touches anything. One kernel with both paths inlined (round 3) reported its resources as
+// the maximum over both -- 19-22 spilled VGPRs and 52-88 B of scratch that only the general path has -- and had grown to
+// 125 KB of code, against the 128 KB reach of s_cbranch. `only` = 1 / 2 picks the member.
 template <typename T>
-SolveFn<T> pick_solve(int lps, bool glb, int rs = 0)
+SolveFn<T> pick_solve(int lps, bool glb, int rs = 0, int only = 1)
 {
     if constexpr (sizeof(T) == 4)
-        if (rs == kRegSlotsSmall && lps == 3 && !glb) return solve_kernel<T, 3, false, kRegSlotsSmall>;
-    if (rs == kRegSlotsLarge && lps == 3 && !glb) {
-        if constexpr (sizeof(T) == 8) return solve_kernel<T, 3, false, kRegSlotsLarge, 1>; // (fp64: one wavefront per SIMD; a pair)
-        else return solve_kernel<T, 3, false, kRegSlotsLarge>;
-    }
+        if (rs == kRegSlotsSmall && lps == 3 && !glb)
+            return only == 2 ? solve_kernel<T, 3, false, kRegSlotsSmall, 2> : solve_kernel<T, 3, false, kRegSlotsSmall, 1>;
+    if (rs == kRegSlotsLarge && lps == 3 && !glb)
+        return only == 2 ? solve_kernel<T, 3, false, kRegSlotsLarge, 2> : solve_kernel<T, 3, false, kRegSlotsLarge, 1>;
     if (glb) return lps == 3 ? solve_kernel<T, 3, true> : lps == 2 ? solve_kernel<T, 2, true> : solve_kernel<T, 1, true>;
     return lps == 3 ? solve_kernel<T, 3, false> : lps == 2 ? solve_kernel<T, 2, false> : solve_kernel<T, 1, false>;
 }
 template <typename T>
-SolveFn<T> pick_solve_spec(int lps, bool glb, int rs = 0)
+SolveFn<T> pick_solve_spec(int lps, bool glb, int rs = 0, int only = 1)
 {
     if constexpr (sizeof(T) == 4) {
-        if (rs == kRegSlotsSmall && lps == 3 && !glb) return solve_spec_kernel<T, 3, false, kRegSlotsSmall>;
-        if (rs == kRegSlotsLarge && lps == 3 && !glb) return solve_spec_kernel<T, 3, false, kRegSlotsLarge>;
+        if (rs == kRegSlotsSmall && lps == 3 && !glb)
+            return only == 2 ? solve_spec_kernel<T, 3, false, kRegSlotsSmall, 2> : solve_spec_kernel<T, 3, false, kRegSlotsSmall, 1>;
+        if (rs == kRegSlotsLarge && lps == 3 && !glb)
+            return only == 2 ? solve_spec_kernel<T, 3, false, kRegSlotsLarge, 2> : solve_spec_kernel<T, 3, false, kRegSlotsLarge, 1>;
     }
     if (glb) return lps == 3 ? solve_spec_kernel<T, 3, true> : lps == 2 ? solve_spec_kernel<T, 2, true> : solve_spec_kernel<T, 1, true>;
     return lps == 3 ? solve_spec_kernel<T, 3, false> : lps == 2 ? solve_spec_kernel<T, 2, false> : solve_spec_kernel<T, 1, false>;
@@ -685,14 +701,13 @@ SolveFn<T> pick_solve_coop(int lps, bool glb)
 }
 
 template <typename T>
-EvalFn<T> pick_eval(int lps, bool glb, int rs = 0)
+EvalFn<T> pick_eval(int lps, bool glb, int rs = 0, int only = 1)
 {
     if constexpr (sizeof(T) == 4)
-        if (rs == kRegSlotsSmall && lps == 3 && !glb) return eval_kernel<T, 3, false, kRegSlotsSmall>;
-    if (rs == kRegSlotsLarge && lps == 3 && !glb) {
-        if constexpr (sizeof(T) == 8) return eval_kernel<T, 3, false, kRegSlotsLarge, 1>;
-        else return eval_kernel<T, 3, false, kRegSlotsLarge>;
-    }
+        if (rs == kRegSlotsSmall && lps == 3 && !glb)
+            return only == 2 ? eval_kernel<T, 3, false, kRegSlotsSmall, 2> : eval_kernel<T, 3, false, kRegSlotsSmall, 1>;
+    if (rs == kRegSlotsLarge && lps == 3 && !glb)
+        return only == 2 ? eval_kernel<T, 3, false, kRegSlotsLarge, 2> : eval_kernel<T, 3, false, kRegSlotsLarge, 1>;
     if (glb) return lps == 3 ? eval_kernel<T, 3, true> : lps == 2 ? eval_kernel<T, 2, true> : eval_kernel<T, 1, true>;
     return lps == 3 ? eval_kernel<T, 3, false> : lps == 2 ? eval_kernel<T, 2, false> : eval_kernel<T, 1, false>;
 }
@@ -770,9 +785,12 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
     // fp64 runs 2 wavefronts per SIMD (256 VGPRs) against 3 in fp32, so fewer 4-wavefront workgroups are resident
     const int cap = sizeof(T) == 4 ? h->n_simd : h->n_simd / 2;
     if (lw == 0) {
-        // one workgroup per SIMD or less: as many wavefronts per instance as stay resident together (3 per SIMD in
-        // fp32: measured on configs[1], W = 3 28.5 k solves/s against 25.1 k with W = 4 and 25.8 k with W = 2)
-        lw = B <= cap ? (sizeof(T) == 4 ? (L.rs >= kRegSlotsLarge ? 2 : NMPC_SPEC_WPE_F32) : kSpecWaves) : B <= 4 * cap ? 2 : 1;
+        // one workgroup per SIMD or less: four wavefronts per instance. (Round 2 measured W = 3 -- what stays resident
+        // together at 168 registers -- ahead of W = 4, 28.5 k against 25.1 k solves/s on configs[1]; since the resumable
+        // solve starts the long instances first, the quarter of the workgroups that has to wait for a slot is the short
+        // ones and the faster line search of the long ones wins: 41.8 k (W = 4) against 40.0 k (W = 3) and 35.4 k (W = 2),
+        // `passing` 46.6 / 41.8 / 34.7 k -- profiles/r04_exp_cfg1_waves.txt. Results do not depend on W, bit for bit.)
+        lw = B <= cap ? (sizeof(T) == 4 ? (L.rs >= kRegSlotsLarge ? 2 : kSpecWaves) : kSpecWaves) : B <= 4 * cap ? 2 : 1;
         // Large batches whose LDS tables allow only a few workgroups per CU (e.g. 40 active obstacle rows: 35 KB,
         // 4 per CU = one wavefront per SIMD): the wavefronts of a latency-kernel workgroup SHARE the instance's
         // tables, so W of them fill the SIMDs that the throughput kernel leaves empty (measured on configs[2]:
@@ -809,9 +827,11 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
     pl.lds_bytes = (size_t)(waves ? L.lds_total_spec : L.lds_total) * sizeof(T);
     pl.fn = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs) : pick_solve<T>(h->lps, L.glb, L.rs);
     pl.has_axis = L.rs > 0 && h->lps == 3 && !L.glb;
+    if (pl.has_axis) pl.fn2 = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs, 2) : pick_solve<T>(h->lps, L.glb, L.rs, 2);
     pl.uses_ws = L.glb;
     if (coop > 1) {
         pl.fn = pick_solve_coop<T>(h->lps, L.glb);
+        pl.fn2 = nullptr;
         pl.has_axis = false;
         pl.lds_bytes = (size_t)L.lds_total_coop * sizeof(T);
         k.lds_xch = L.lds_xch_coop;
@@ -841,7 +861,7 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
             fill_layout(k, R);
             waves = 0;
             pl.fn = pick_solve<T>(h->lps, false, R.rs);
-            pl.fn2 = solve_kernel<T, 3, false, kRegSlotsLarge, 2>;
+            pl.fn2 = pick_solve<T>(h->lps, false, R.rs, 2);
             pl.lds_bytes = (size_t)R.lds_total * sizeof(T);
             pl.has_axis = true;
             pl.uses_ws = false;
