@@ -1239,6 +1239,7 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
     size_t lds_bytes = (size_t)L.lds_total * sizeof(T);
     EvalFn<T> fn = pick_eval<T>(h->lps, L.glb, L.rs), fn2 = nullptr;
     bool has_axis = L.rs > 0 && h->lps == 3 && !L.glb;
+    if (has_axis) fn2 = pick_eval<T>(h->lps, L.glb, L.rs, 2); // (register-table kernels are pairs: the general-path member)
     if constexpr (sizeof(T) == 8) { // (what solves of large fp64 batches run: the register-table kernel where it is offered)
         if (h->lay64r.rs > 0 && h->cfg.coop_waves <= 1 && h->cfg.latency_waves <= 1 && (h->cfg.reg_table > 0 || h->use64r_auto)) {
             const Layout& R = h->lay64r;
@@ -1255,6 +1256,7 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
     if (h->cfg.coop_waves > 1 && L.rs == 0 && h->coop_ok[sizeof(T) == 4 ? 0 : 1]) {
         waves = std::min<int>(h->cfg.coop_waves, kSpecWaves);
         fn = pick_eval_coop<T>(h->lps, L.glb);
+        fn2 = nullptr;
         has_axis = false;
         lds_bytes = (size_t)L.lds_total_coop * sizeof(T);
         k.lds_xch = L.lds_xch_coop;
@@ -1462,12 +1464,13 @@ int set_lds_limit(nmpc_handle_s* h)
 {
     const Layout& L = h->lay<T>();
     const size_t lds_bytes = (size_t)L.lds_total * sizeof(T);
-    if (lds_bytes > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve<T>(h->lps, L.glb, L.rs)),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_eval<T>(h->lps, L.glb, L.rs)),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    }
+    if (lds_bytes > 48 * 1024)
+        for (int only = 1; only <= 2; ++only) { // (register-table kernels: both members of the pair; else the same kernel twice)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve<T>(h->lps, L.glb, L.rs, only)),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_eval<T>(h->lps, L.glb, L.rs, only)),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        }
     if (sizeof(T) == 4 && h->lay32c.rs > 0) {
         const size_t cb = (size_t)h->lay32c.lds_total_coop * sizeof(float);
         if (cb > 48 * 1024)
@@ -1490,8 +1493,9 @@ int set_lds_limit(nmpc_handle_s* h)
     if (spec_bytes > kLdsLimit) {
         h->spec_ok[sizeof(T) == 4 ? 0 : 1] = false; // no room for the exchange area: latency mode unavailable
     } else if (spec_bytes > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve_spec<T>(h->lps, L.glb, L.rs)),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)spec_bytes));
+        for (int only = 1; only <= 2; ++only)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve_spec<T>(h->lps, L.glb, L.rs, only)),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)spec_bytes));
     }
     return 0;
 }

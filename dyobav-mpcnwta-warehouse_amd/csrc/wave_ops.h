@@ -277,6 +277,35 @@ __device__ __forceinline__ void class3_sum2(float& x, float& y, const int (&a)[4
     x = (x0 + x1) + (x2 + x3);
     y = (y0 + y1) + (y2 + y3);
 }
+// One value (the register-table passes gate their two slots separately since round 4): the same DPP steps and the same
+// association of the four row partials as class3_sum2 -- a slot's E_j comes out bit-identical either way.
+template <typename T>
+__device__ __forceinline__ void class3_sum1(T& x, const int (&a)[4])
+{
+    x += dpp_mov<DPP_ROW_SHR0 + 3, 0xf, 0xf, true>(T(0), x);
+    x += dpp_mov<DPP_ROW_SHR0 + 6, 0xf, 0xf, true>(T(0), x);
+    x += dpp_mov<DPP_ROW_SHR0 + 12, 0xf, 0xf, true>(T(0), x);
+    const T x0 = bperm(x, a[0]), x1 = bperm(x, a[1]), x2 = bperm(x, a[2]), x3 = bperm(x, a[3]);
+    x = (x0 + x1) + (x2 + x3);
+}
+template <typename T>
+struct Class3Pending1 {
+    T x[4];
+};
+template <typename T>
+__device__ __forceinline__ void class3_issue1(T x, const int (&a)[4], Class3Pending1<T>& p)
+{
+    x += dpp_mov<DPP_ROW_SHR0 + 3, 0xf, 0xf, true>(T(0), x);
+    x += dpp_mov<DPP_ROW_SHR0 + 6, 0xf, 0xf, true>(T(0), x);
+    x += dpp_mov<DPP_ROW_SHR0 + 12, 0xf, 0xf, true>(T(0), x);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p.x[q] = bperm(x, a[q]);
+}
+template <typename T>
+__device__ __forceinline__ T class3_finish1(const Class3Pending1<T>& p)
+{
+    return (p.x[0] + p.x[1]) + (p.x[2] + p.x[3]);
+}
 // The same in two halves, so that independent work can sit between the crossbar requests and their results (the
 // round trip is ~130 cycles; a wavefront that waits for it does not issue, and with two wavefronts per SIMD nobody else
 // takes its slots): class3_issue() leaves the eight row partials in flight, class3_finish() adds them up.

@@ -1,14 +1,16 @@
 #!/bin/bash
 # Round profile pass on the GPU box: bench lines + rocprofv3 kernel stats + PMC passes, written to gpurun_out/$1/.
-# Usage (from the repo root, inside gpurun): bash tools/run_profiles.sh r03
+# Usage (from the repo root, inside gpurun): bash tools/run_profiles.sh r04
 set -u
-R=$(pwd); RN=${1:-r03}; OUT=$R/gpurun_out/$RN; mkdir -p $OUT
+R=$(pwd); RN=${1:-r04}; OUT=$R/gpurun_out/$RN; mkdir -p $OUT
+RNUM=$(echo $RN | sed 's/^r0*//')
 export TMPDIR=/tmp
 cd /tmp
 B="python3 $R/bench.py"
 LEAN="--no-cpu-baseline --no-secondary --no-accuracy"
 # 1. headline line (secondary workloads, CPU baseline, accuracy table), same command the driver runs
 $B > $OUT/cfg2_bench.json 2> $OUT/cfg2_bench.err
+cp $R/bench_detail.json $OUT/cfg2_bench_detail.json 2>/dev/null
 # 2. kernel trace + stats of the headline workload (same kernel, same batch)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B $LEAN --steps 3 > $OUT/cfg2_bench_under_rocprof.json 2> $OUT/stats.err
 find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/cfg2_kernel_stats.csv
@@ -18,15 +20,19 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- $B $LEAN --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_sq.err
 (python3 $R/tools/pmc_summary.py steps=2 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE; python3 $R/tools/pmc_summary.py steps=1 $OUT/pmc_sq) > $OUT/cfg2_pmc_summary.txt 2>&1
-python3 $R/tools/make_traffic_json.py 3 cfg2 f32 65536 5928 20 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/cfg2_traffic.json 2 > /dev/null 2>> $OUT/pmc_sq.err
+python3 $R/tools/make_traffic_json.py $RNUM cfg2 f32 65536 5928 20 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/cfg2_traffic.json 2 > /dev/null 2>> $OUT/pmc_sq.err
 python3 $R/tools/kernel_stats_per_step.py $OUT/cfg2_kernel_stats.csv 4 > $OUT/cfg2_kernel_stats_per_step.txt 2>&1
+# 3b. instruction cache of the FINAL headline kernel and the dynamic instruction mix
+rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES --output-format csv -d $OUT/pmc_icache -- $B $LEAN --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_icache.err
+python3 $R/tools/pmc_summary.py steps=1 $OUT/pmc_icache > $OUT/cfg2_icache_summary.txt 2>&1
+(cd $R && bash tools/pmc_mix.sh $RN/pmc_mix) > $OUT/cfg2_pmc_instruction_mix.txt 2>&1
 # 4. configs[4] traffic (the one configuration whose obstacle table is streamed from global memory) and configs[1]
 for wl in cfg4:8192:40968:40 cfg1:1024:2778:20; do
   IFS=: read name batch np n <<< "$wl"
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_${name}_$c -- $B $LEAN --workload $name --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_${name}_$c.err
   done
-  python3 $R/tools/make_traffic_json.py 3 $name f32 $batch $np $n $OUT/pmc_${name}_FETCH_SIZE $OUT/pmc_${name}_WRITE_SIZE $OUT/${name}_traffic.json 1 > /dev/null 2>> $OUT/pmc_sq.err
+  python3 $R/tools/make_traffic_json.py $RNUM $name f32 $batch $np $n $OUT/pmc_${name}_FETCH_SIZE $OUT/pmc_${name}_WRITE_SIZE $OUT/${name}_traffic.json 1 > /dev/null 2>> $OUT/pmc_sq.err
 done
 # 5. the next-row components
 python3 $R/tools/bench_assemble.py 2>/dev/null | tail -1 > $OUT/f1_assemble_bench.json
@@ -36,4 +42,6 @@ python3 $R/tools/bench_evaluate.py 1 60 f64 2>/dev/null | tail -1 > $OUT/f3_eval
 python3 $R/tools/bench_evaluate.py 65536 60 f32 2>/dev/null | tail -1 > $OUT/f3_evaluate_b65536.json
 python3 $R/tools/solo_latency.py 2>/dev/null | grep "instance" > $OUT/solo_latency.txt
 python3 $R/tools/kernel_resources.py > $OUT/kernel_resources.txt 2>/dev/null
+python3 $R/tools/exp_cfg1_waves.py > $OUT/exp_cfg1_waves.txt 2>/dev/null
+python3 $R/tools/exp_polish_stats.py cfg2 1024 > $OUT/polish_stats_cfg2.txt 2>/dev/null
 ls $OUT
