@@ -72,11 +72,12 @@ def test_latency_mode_other_dimensions():
 
 
 def test_automatic_choice_follows_batch_size():
-    """latency_waves = 0: small batches get as many wavefronts per instance as stay resident together on a SIMD
-    (3 in fp32; 2 with the 14-slot register table, whose kernels run two wavefronts per SIMD; 4 in fp64), mid-size
-    batches 2, large ones the throughput kernel (info[7] = wavefronts per instance, 0 = throughput kernel)."""
+    """latency_waves = 0: small batches get four wavefronts per instance (round 4: with the long instances started first
+    the faster line search wins over what stays resident together; 2 with the 14-slot register table, whose kernels run
+    two wavefronts per SIMD), mid-size batches 2, large ones the throughput kernel (info[7] = wavefronts per instance,
+    0 = throughput kernel)."""
     P_small = nm.scenarios.make_batch(32, seed=37)
-    for hint, dtype, expect in ((10, np.float32, 3), (0, np.float32, 2), (0, np.float64, 4)):
+    for hint, dtype, expect in ((10, np.float32, 4), (0, np.float32, 2), (0, np.float64, 4)):
         cfg = nm.default_config_struct()
         cfg.latency_waves = 0
         cfg.max_active_dynobs = hint
