@@ -7,7 +7,6 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -771,7 +770,6 @@ struct Plan {
     int mode = 0;          // 0 throughput, 1 latency (speculative), 2 cooperative
     bool uses_ws = false;  // the variant reads the global obstacle workspace
     bool stageable = false;
-    int threads_pilot = 0; // latency kernel, resumable solve: workgroup size of the pilot launch (0 = threads); results do not depend on it
     int resident = 0;      // cooperative kernels: workgroups resident at once (0 = derived from the one-wavefront layout)
 };
 
@@ -872,11 +870,6 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
     }
     pl.threads = waves ? 64 * waves : 64;
     pl.mode = coop > 1 ? 2 : waves ? 1 : 0;
-    if (pl.mode == 1) // (experiment knob, diagnostic: wavefronts per instance of the pilot launch)
-        if (const char* e = std::getenv("NMPC_PILOT_WAVES")) {
-            const int w = std::atoi(e);
-            if (w >= 2 && w <= kSpecWaves) pl.threads_pilot = 64 * w;
-        }
     pl.stageable = h->cfg.max_solver_time_us <= 0; // (every kernel family parks / resumes; a wall-clock budget does not survive it)
     if (pl.mode == 2) { // cooperative kernels: workgroups resident on the device (LDS-bound; one per CU for the on-chip variant)
         const int per_cu = std::max<int>(1, (int)(kLdsLimit / std::max<size_t>(pl.lds_bytes, 1)));
@@ -887,15 +880,14 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
 
 // one launch of the planned kernel over `grid` workgroups
 template <typename T>
-int launch_plan(nmpc_handle_s* h, const Plan<T>& pl, const nmpc::KParams<T>& k, int grid, bool pilot = false)
+int launch_plan(nmpc_handle_s* h, const Plan<T>& pl, const nmpc::KParams<T>& k, int grid)
 {
-    const int threads = pilot && pl.threads_pilot ? pl.threads_pilot : pl.threads;
     if (!pl.fn2 || k.axis_mode != 0) { // (axis_mode 0 = the general path only: the axis-only kernel of a pair has nothing to do)
-        hipLaunchKernelGGL(pl.fn, dim3(grid), dim3(threads), pl.lds_bytes, h->stream, k);
+        hipLaunchKernelGGL(pl.fn, dim3(grid), dim3(pl.threads), pl.lds_bytes, h->stream, k);
         HIP_TRY(hipGetLastError());
     }
     if (pl.fn2 && k.axis_mode != 1) {
-        hipLaunchKernelGGL(pl.fn2, dim3(grid), dim3(threads), pl.lds_bytes, h->stream, k);
+        hipLaunchKernelGGL(pl.fn2, dim3(grid), dim3(pl.threads), pl.lds_bytes, h->stream, k);
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -987,7 +979,7 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
         ki.stage_in = i > 0;
         ki.stage_outer_cap = i < n_stage ? stage_cap[i] : 0;
         if (i > 0) ki.order = order2;
-        if (int rc = launch_plan<T>(h, pl, ki, B, i == 0)) return rc;
+        if (int rc = launch_plan<T>(h, pl, ki, B)) return rc;
         if (i == n_stage) break;
         hipLaunchKernelGGL(rank_hist_kernel<T>, dim3(nb), dim3(256), 0, h->stream, k.resume, k.status, B, hist, stage_key[i]);
         hipLaunchKernelGGL(rank_scan_kernel, dim3(1), dim3(kRankBuckets), 0, h->stream, hist, offs);
