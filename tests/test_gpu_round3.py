@@ -231,14 +231,16 @@ def test_staged_solve_other_dimensions_and_automatic_choice():
         assert np.array_equal(auto[k], one[k]), k
 
 
-def test_polish_reaches_the_tight_fixed_point_and_touches_nothing_else():
+@pytest.mark.parametrize("mode", [1, 2])
+def test_polish_reaches_the_tight_fixed_point_and_touches_nothing_else(mode):
+    """mode 1 = one fp64 inner solve at the final penalty / multipliers (round 4), mode 2 = the full ALM continuation"""
     lay = ParamLayout(N=20, Ndyn=15)
     B = 768
     P = nm.scenarios.make_batch(B, lay, seed=1234, n_ped=2, n_hyp=5, ped_mode="passing")
     P32 = P.astype(np.float32)
     with nm.Handle(_cfg(lay, 10)) as h:
         plain = h.solve(P32)
-    with nm.Handle(_cfg(lay, 10, polish=1)) as h:
+    with nm.Handle(_cfg(lay, 10, polish=mode)) as h:
         pol = h.solve(P32)
         pol_min = {}                                              # optional outputs left out: same controls
         U = np.empty((B, 2 * lay.N), np.float32)
@@ -255,6 +257,8 @@ def test_polish_reaches_the_tight_fixed_point_and_touches_nothing_else():
     assert sel.sum() >= B // 4 and (flag[~sel] == 0).all() and (flag[sel] >= 1).all()
     for k in ("U", "cost", "y"):                                 # not selected, or continuation not converged: untouched
         assert np.array_equal(pol[k][flag != 1], plain[k][flag != 1]), k
+    if mode == 1:                                                # (one inner solve: the multipliers are not updated)
+        assert np.array_equal(pol["y"], plain["y"])
     assert np.array_equal(pol["iters"][flag == 0], plain["iters"][flag == 0])
     assert (pol["iters"][flag == 2, 1] > plain["iters"][flag == 2, 1]).all()      # (the work done is counted either way)
     done = flag == 1
@@ -271,7 +275,7 @@ def test_polish_reaches_the_tight_fixed_point_and_touches_nothing_else():
     assert both.sum() >= 60 and np.median(du[both]) < 3e-5 and np.mean(du[both] < 1e-4) >= 0.8
     assert np.median(du_plain[both]) > 3e-4 and np.mean(du_plain[both] < 1e-4) < 0.1
     # fp64 main solve + polish: same mechanism
-    with nm.Handle(_cfg(lay, 10, polish=1)) as h:
+    with nm.Handle(_cfg(lay, 10, polish=mode)) as h:
         pol64 = h.solve(P, dtype=np.float64)
     d64 = (pol64["info"][:, 6] == 1) & done
     assert d64.sum() >= 60
