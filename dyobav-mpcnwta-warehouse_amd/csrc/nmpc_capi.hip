@@ -1614,7 +1614,7 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
     if (cfg->axis_aligned < -1 || cfg->axis_aligned > 1)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "axis_aligned = %d (0 automatic, 1 promised, -1 never)", cfg->axis_aligned);
     if (cfg->staged < -1) return fail(NMPC_ERR_INVALID_ARGUMENT, "staged = %d < -1", cfg->staged);
-    if (cfg->polish != 0 && cfg->polish != 1) return fail(NMPC_ERR_INVALID_ARGUMENT, "polish = %d (0 or 1)", cfg->polish);
+    if (cfg->polish < 0 || cfg->polish > 2) return fail(NMPC_ERR_INVALID_ARGUMENT, "polish = %d (0, 1 or 2)", cfg->polish);
     if (cfg->polish && (!(cfg->polish_tolerance > 0) || !(cfg->polish_delta_tolerance > 0) ||
                         cfg->polish_max_outer_iterations < 1 || cfg->polish_max_inner_iterations < 1))
         return fail(NMPC_ERR_INVALID_ARGUMENT, "bad polish tolerances / iteration caps");
