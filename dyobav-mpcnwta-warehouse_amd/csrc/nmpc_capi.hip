@@ -1554,7 +1554,7 @@ int nmpc_default_config(nmpc_config* c)
     c->staged = 0;
     c->polish = 0;
     c->polish_max_outer_iterations = 4;
-    c->polish_max_inner_iterations = 300;
+    c->polish_max_inner_iterations = 150; // (round 4: 300 -> 150, see nmpc_hip.h)
     c->staged_evals = 0;
     c->polish_tolerance = 1e-6;
     c->polish_delta_tolerance = 1e-5;

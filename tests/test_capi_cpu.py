@@ -34,7 +34,7 @@ def test_config_struct_matches_header_defaults():
     assert cfg.max_outer_iterations == 10 and cfg.lbfgs_memory == 10
     assert cfg.latency_waves == 0 and cfg.akkt_form == 0 and cfg.max_solver_time_us == 0.0
     assert cfg.coop_waves == 0 and cfg.axis_aligned == 0 and cfg.reg_table == 0 and cfg.staged == 0
-    assert cfg.polish == 0 and cfg.polish_max_outer_iterations == 4 and cfg.polish_max_inner_iterations == 300
+    assert cfg.polish == 0 and cfg.polish_max_outer_iterations == 4 and cfg.polish_max_inner_iterations == 150
     assert cfg.polish_tolerance == 1e-6 and cfg.polish_delta_tolerance == 1e-5 and cfg.staged_evals == 0
     # struct size and a late field's offset: ctypes mirror vs the C compiler on include/nmpc_hip.h (catches field drift)
     import subprocess, tempfile
