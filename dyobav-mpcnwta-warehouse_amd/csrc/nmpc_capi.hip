@@ -1103,8 +1103,13 @@ int polish_batch(nmpc_handle_s* h, const nmpc::KParams<T>& k, int B, bool y_user
     nmpc::KParams<double> q;
     fill_kparams(h, q);
     const nmpc_config& c = h->cfg;
-    q.tol = q.init_tol = c.polish_tolerance;
-    q.max_inner = c.polish_max_inner_iterations;
+    // The exit test bounds ||gamma fpr||, which pins u only to ~tol / gamma, and the curvature of the path term grows with
+    // the lever arm of the horizon: at N = 40 a tolerance of 1e-6 leaves the controls 2-3e-4 from the fixed point where
+    // N = 20 gets 2e-5. Beyond the reference's horizon the continuation's tolerance therefore shrinks with (20 / N)^3
+    // (N = 40: 1.25e-7) and its iteration cap grows with (N / 20)^2.
+    const double hscale = c.N_hor > 20 ? 20.0 / c.N_hor : 1.0;
+    q.tol = q.init_tol = c.polish_tolerance * hscale * hscale * hscale;
+    q.max_inner = (int)(c.polish_max_inner_iterations / (hscale * hscale) + 0.5);
     if (c.polish == 1) {
         // ONE inner solve at the penalty and multipliers the main solve ended with (KParams::single_inner): what the
         // continuation needs is stationarity to polish_tolerance; the hard-constraint criterion stays at the main solve's delta.
