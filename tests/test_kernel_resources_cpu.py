@@ -58,10 +58,12 @@ def test_fp32_latency_and_cooperative_kernels_spill_little(resources):
         assert r["sgpr_spill"] <= 24, (name, r)
         # (general path of the register-table variants: ~16 VGPRs in scratch; the axis-aligned 4-slot member: 2)
         assert r["scratch"] <= (72 if general else 16 if axis else 0), (name, r)
-    for name, r in _sel(resources, r"solve_coop(_reg)?_kernel(<float|$|\()").items():
+    sel = _sel(resources, r"solve_coop(_reg)?_kernel<(float|true|false)")
+    assert any("coop_reg" in n for n in sel)          # (the on-chip kernels are named <true> / <false>: they must not drop out)
+    for name, r in sel.items():
         # (SGPR -> VGPR-lane spills only, no scratch; the segment chunk bounds and the exchange of the partial minima
         # added ~8 to the on-chip kernel in exchange for the 24 % they bought on configs[4])
-        assert r["sgpr_spill"] <= 36 and r["scratch"] == 0, (name, r)
+        assert r["sgpr_spill"] <= 40 and r["scratch"] == 0, (name, r)
 
 
 def test_evaluation_and_data_kernels_are_spill_free(resources):
