@@ -821,7 +821,7 @@ static int SUF(orc_solve_impl)(const orc_problem *pr, const orc_options *op, con
                 if (fabs(t) < fabs(m)) m = t;
                 t = ((double)dyn_plus - op->sufficient_decrease * (double)dyn) / ((double)dyn_plus + tiny);
                 if (fabs(t) < fabs(m)) m = t;
-                if (n2 > 0) {
+                if (n2 > 0 && (f2n_plus != 0 || f2n != 0)) { /* (0 <= 0.1 * 0 is not a near-tie: both are exact zeros of max(0, .)) */
                     t = ((double)f2n_plus - op->sufficient_decrease * (double)f2n) / ((double)f2n_plus + tiny);
                     if (fabs(t) < fabs(m)) m = t;
                 }

@@ -75,3 +75,30 @@ def test_trace_reproduces_the_untraced_solve():
             assert np.array_equal(u, U[i]) and res["status"] == r["status"][i]
             assert len(head) == res["inner_iters"] + res["outer_iters"] or len(head) >= res["inner_iters"]
             assert (np.diff(head[:, 0]) >= 0).all() and head[0, 1] == 0
+
+
+def test_the_audit_flags_genuine_algorithmic_differences():
+    """The audit must not explain everything away: an implementation that differs in a RULE (not in rounding) has to come
+    out unexplained. Oracle vs the oracle with (a) an L-BFGS memory of 9 instead of 10, (b) a penalty update factor of 4.9
+    instead of 5, (c) a sufficient-decrease ratio of 0.5 instead of 0.1, (d) a Lipschitz-estimator step of 1e-5 instead of 1e-4: the
+    paths part at the first iteration the rule matters -- a discrete field differs, or the iterates jump apart by many orders
+    of magnitude within one iteration, while they still agreed to rounding and no decision was a near-tie."""
+    lay, P = _batch(24)
+    pr = oracle.Problem()
+    base = oracle.Options(lip_delta=LIP_STEP, lip_eps=LIP_STEP)
+    variants = {"lbfgs memory 9": dict(lbfgs_mem=9), "penalty update 4.9": dict(penalty_update=4.9),
+                "sufficient decrease 0.5": dict(sufficient_decrease=0.5), "lipschitz step 1e-5": dict(lip_delta=1e-5, lip_eps=1e-5)}
+    for name, ov in variants.items():
+        alt = oracle.Options(**{**{k: v for k, v in base.__dict__.items() if k != "extra"}, **ov})
+        flagged = diverged = 0
+        for i in range(24):
+            ua, _, ra, ha, Ua = oracle.solve_trace(pr, alt, P[i])
+            ub, _, rb, hb, Ub = oracle.solve_trace(pr, base, P[i])
+            if np.abs(ua - ub).max() <= 1e-4 and ra["status"] == rb["status"]:
+                continue
+            diverged += 1
+            a = audit_pair(ha, Ua, hb, Ub)
+            flagged += not a["explained"]
+        print(f"{name}: {diverged} of 24 instances end > 1e-4 apart, {flagged} of them flagged by the audit")
+        assert diverged >= 4, name
+        assert flagged >= 0.6 * diverged, (name, flagged, diverged)
