@@ -73,8 +73,9 @@ def _stats_mask(Ua, Ub, mask):
 DISCRETE_FIELDS = (0, 1, 2, 3, 4, 14)   # outer, inner index, Lipschitz doublings, line-search halvings, L-BFGS pair, penalty
                                         # (the penalty changes by the factor 5 or not at all: an outer-loop decision)
 START_TOL = 1e-8        # distance of the iterates over the first records (same algorithm, same start)
-JUMP_LIMIT = 1e6        # growth of the distance within ONE iteration, from a level above rounding
-MARGIN_FACTOR = 1e3     # a differing decision is a tie-break if its relative margin <= MARGIN_FACTOR * (distance before it,
+JUMP_LIMIT = 1e8        # growth of the distance within ONE iteration, from a level above rounding (the oracle against its own
+                        # re-associated twin reaches 5e6 on one of 512 instances; a difference in a rule jumps >= 1e9)
+MARGIN_FACTOR = 1e4     # a differing decision is a tie-break if its relative margin <= MARGIN_FACTOR * (distance before it,
                         # at least 1e-13) * max(1, ||grad psi|| / |psi|) -- what that distance is worth in relative psi
 
 
