@@ -427,7 +427,7 @@ def compact_line(detail: dict) -> str:
     out["converged_solves_per_s"] = _r(detail["converged_solves_per_s"])
     if "cpu_baseline" in detail:
         cb = detail["cpu_baseline"]
-        out["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind", "sample", "single_core_value",
+        out["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind", "sample", "single_core_value", "value_trig_hoisted",
                                                       "value_with_reference_time_cap", "converged_frac", "open_probe")
                                if k in cb}
     if "secondary" in detail:
@@ -556,6 +556,12 @@ def cpu_baseline(layout, P_host):
     t0 = time.perf_counter()
     oracle.solve_batch(pr, oracle.Options(), Ps[:n1], nthreads=1)
     t_one = time.perf_counter() - t0
+    # the same sample with the ellipses' cos / sin hoisted out of the evaluations (orc_options.hoist_trig: once per solve, same
+    # bits). The default recomputes them on every evaluation, as the reference's CasADi-generated code does; a hand-tuned CPU
+    # solver would not -- VERDICT r3 called the plain figure pessimistic, so both are reported.
+    t0 = time.perf_counter()
+    oracle.solve_batch(pr, oracle.Options(hoist_trig=1), Ps, nthreads=cores)
+    t_hoist = time.perf_counter() - t0
     # the same sample with the reference's own wall-clock cap per solve (max_solver_time = 0.1 s, mpc_builder.py:189)
     cap_s = 0.1
     t0 = time.perf_counter()
@@ -567,6 +573,7 @@ def cpu_baseline(layout, P_host):
                     "these solves would end NotConvergedOutOfTime there. Reported, not a target." % (1e3 * t_one / n1),
             "sample": f"first {sample} instances of the timed batch, fp64, {t_all:.1f} s wall",
             "single_core_value": n1 / t_one, "single_core_sample": f"first {n1} instances, 1 thread",
+            "value_trig_hoisted": sample / t_hoist,
             "value_with_reference_time_cap": sample / t_cap,
             "reference_time_cap": {"max_solver_time_s": cap_s, "wall_s": t_cap,
                                    "out_of_time_frac": float(np.mean(rc["status"] == 2)),

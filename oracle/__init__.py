@@ -36,7 +36,7 @@ class _Options(C.Structure):
                 ("inner_tol_update", C.c_double), ("sufficient_decrease", C.c_double),
                 ("lip_delta", C.c_double), ("lip_eps", C.c_double),
                 ("cbfgs_alpha", C.c_double), ("cbfgs_eps", C.c_double), ("sy_eps", C.c_double),
-                ("akkt_form", C.c_int32), ("pad_", C.c_int32), ("max_time_s", C.c_double)]
+                ("akkt_form", C.c_int32), ("hoist_trig", C.c_int32), ("max_time_s", C.c_double)]
 
 
 class _Result(C.Structure):
@@ -129,13 +129,14 @@ class Options:
     sy_eps: float = 1e-10
     akkt_form: int = 0   # 0 = OpEn source form of the AKKT residual, 1 = documented form (see nmpc_oracle.h)
     max_time_s: float = 0.0   # wall-clock budget of one solve (the reference's max_solver_time: 0.1 s); 0 = none
+    hoist_trig: int = 0       # 1: cos / sin of the ellipse angles once per solve instead of per evaluation (same bits)
     extra: dict = field(default_factory=dict)
 
     def c(self) -> _Options:
         return _Options(self.tolerance, self.initial_tolerance, self.delta_tolerance, self.max_outer,
                         self.max_inner, self.lbfgs_mem, self.initial_penalty, self.penalty_update,
                         self.inner_tol_update, self.sufficient_decrease, self.lip_delta, self.lip_eps,
-                        self.cbfgs_alpha, self.cbfgs_eps, self.sy_eps, self.akkt_form, 0, self.max_time_s)
+                        self.cbfgs_alpha, self.cbfgs_eps, self.sy_eps, self.akkt_form, self.hoist_trig, self.max_time_s)
 
 
 TRACE_HEAD = 16   # ORC_TRACE_HEAD

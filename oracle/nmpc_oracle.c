@@ -43,7 +43,7 @@ void orc_default_options(orc_options *o)
     o->cbfgs_eps = 1e-8;
     o->sy_eps = 1e-10;
     o->akkt_form = 0;
-    o->pad_ = 0;
+    o->hoist_trig = 0;
     o->max_time_s = 0.0;
 }
 

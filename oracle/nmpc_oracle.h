@@ -65,7 +65,8 @@ typedef struct {
     int32_t akkt_form;           /* AKKT residual of the inner exit test: 0 = OpEn source form (recalled)
                                     ||gamma*fpr + gamma*(df - df_prev)||, 1 = OpEn documentation ||fpr + df - df_prev||
                                     (= the former / gamma). See DESIGN.md "AKKT residual". */
-    int32_t pad_;
+    int32_t hoist_trig;          /* 0 (default): cos / sin of the ellipse angles on every evaluation, as the reference's
+                                    CasADi-generated code does; 1: once per solve (same bits; CPU-baseline speed option) */
     double max_time_s;           /* wall-clock budget of one solve (the reference: with_max_duration_micros = 0.1 s,
                                     mpc_builder.py:189): the inner loop stops once it is used up and no further outer
                                     iteration is started (status 2); 0 = none (default: iteration caps only) */
