@@ -246,16 +246,16 @@ constexpr int wpe(int f32_default)
 {
     return sizeof(T) == 8 ? (RS > 0 ? 1 : NMPC_WPE_F64) : RS >= kRegSlotsLarge ? 2 : RS > 0 ? 3 : f32_default;
 }
-// (register-table kernels: the general and the axis-aligned variant in one kernel, see KParams::axis_mode)
+// (register-table kernels exist per code path -- general / axis-aligned -- see KParams::axis_mode)
 template <typename T, int LPS, int RS>
 constexpr bool kHasAxisVariant = LPS == 3 && RS > 0;
 
-// ONLY: 0 = both paths in one kernel (chosen per launch from KParams::axis_mode); 1 / 2 = the axis-aligned / the general
-// path alone, returning at once when the launch takes the other one. The fp64 register-table kernels are built that
-// way and launched as a pair: with both paths inlined into one 512-register kernel the compiler's output computed
-// garbage on the general path (nondeterministically, in the evaluation kernel; each path compiled alone is right).
-// That kernel was 142 KB of code -- beyond the +-128 KB reach of s_cbranch, so its far branches were relaxed into
-// s_getpc / s_setpc sequences; tests/test_kernel_resources_cpu.py keeps every kernel below that size now.
+// ONLY: 1 / 2 = the axis-aligned / the general path alone, returning at once when the launch takes the other one -- how every
+// register-table kernel is built and launched since round 4 (pick_solve below). (0 = both paths inlined into one kernel,
+// chosen per workgroup: round 3's fp32 form, no longer instantiated. In fp64 that form never worked: the 512-register
+// kernel computed garbage on the general path, nondeterministically, while each path compiled alone is right -- it was
+// 142 KB of code, beyond the +-128 KB reach of s_cbranch, its far branches relaxed into s_getpc / s_setpc sequences;
+// tests/test_kernel_resources_cpu.py keeps every kernel below that size.)
 template <typename T, int LPS, bool GLB, int RS = 0, int ONLY = 0>
 __global__ __launch_bounds__(64, (wpe<T, RS>(NMPC_WPE_F32))) void solve_kernel(nmpc::KParams<T> kp)
 {
@@ -763,7 +763,7 @@ int stage_out(nmpc_handle_s* h, DevBuf& buf, T* dst, size_t count, T** dev, bool
 // ---- kernel choice and launch ---------------------------------------------------------------------------------------
 template <typename T>
 struct Plan {
-    SolveFn<T> fn = nullptr, fn2 = nullptr; // fn2: the general-path twin of an axis-only kernel (fp64 register table)
+    SolveFn<T> fn = nullptr, fn2 = nullptr; // fn2: the general-path member of a register-table kernel pair (fn = the axis-aligned one)
     bool has_axis = false; // the kernel contains the axis-aligned variant (KParams::axis_mode)
     int threads = 64;
     size_t lds_bytes = 0;
