@@ -472,7 +472,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                             o[6] = T(rounds); // exchange rounds (each = up to W evaluations in parallel)
                             o[7] = T(W);
 #ifdef NMPC_PROFILE
-                            for (int i = 0; i < kProfSlots; ++i) o[8 + i] = T(I.prof[i]);
+                            for (int i = 0; i < kProfSlots; ++i) o[8 + i] = T(I.prof_value(i));
 #endif
                         }
                     }
