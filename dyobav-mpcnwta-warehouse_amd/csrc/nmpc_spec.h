@@ -174,12 +174,12 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         akkt_tol = sc[1];
         dyn = sc[2];
         f2n = sc[3];
-        alm_iter = (int)sc[4];
-        outer = (int)sc[5] + 1;
-        inner_total = (int)sc[6];
-        alg_psi = (int)sc[7];
-        alg_grad = (int)sc[8];
-        rounds = (int)sc[9];
+        alm_iter = __builtin_amdgcn_readfirstlane((int)sc[4]);
+        outer = __builtin_amdgcn_readfirstlane((int)sc[5]) + 1;
+        inner_total = __builtin_amdgcn_readfirstlane((int)sc[6]);
+        alg_psi = __builtin_amdgcn_readfirstlane((int)sc[7]);
+        alg_grad = __builtin_amdgcn_readfirstlane((int)sc[8]);
+        rounds = __builtin_amdgcn_readfirstlane((int)sc[9]);
         yv = tclamp(yv, T(-1e12), T(1e12));
         yw = tclamp(yw, T(-1e12), T(1e12));
     }
@@ -213,39 +213,16 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         }
     };
 
-    // The integer / boolean solver state is the same in every lane by construction; telling the compiler so (a
-    // v_readfirstlane each) turns the state machine's control flow into scalar branches instead of lane-mask algebra.
-    auto uni = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
-    auto unib = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+    // The integer / boolean solver state is the same in every lane by construction; the tests on floating-point values
+    // are declared uniform where they are made (one ballot each), so that it lives in scalar registers all the way round
+    // the loop -- see solve_instance (nmpc_device.h).
+    auto anyb = [](bool cond) { return __builtin_amdgcn_ballot_w64(cond) != 0ull; };
     const int timed_ = __builtin_amdgcn_readfirstlane(time_budget > 0 ? 1 : 0);
     for (;;) {
         // wavefront index / budget flag as opaque per-round values: conditions on them are then evaluated where they
         // are used (s_cmp) instead of living in SGPR pairs as loop-invariant lane masks for the whole solve
         int wv = wave, timed = timed_;
         asm volatile("" : "+s"(wv), "+s"(timed));
-        phase = uni(phase);
-        iteration = uni(iteration);
-        num_iter = uni(num_iter);
-        nls = uni(nls);
-        lip_it = uni(lip_it);
-        lb_active = uni(lb_active);
-        lb_head = uni(lb_head);
-        alm_iter = uni(alm_iter);
-        outer = uni(outer);
-        inner_total = uni(inner_total);
-        status = uni(status);
-        xbuf = uni(xbuf);
-        t_now = uni(t_now);
-        cont_time = unib(cont_time);
-        rounds = uni(rounds);
-        alg_psi = uni(alg_psi);
-        alg_grad = uni(alg_grad);
-        want_grad = unib(want_grad);
-        do_eval = unib(do_eval);
-        exchange = unib(exchange);
-        lb_first = unib(lb_first);
-        cont = unib(cont);
-        fbe_valid = unib(fbe_valid);
         const T e_icd = ec == c ? inv_cdiv : T(1);
         if (do_eval) {
             if (kSpecPark) park();
@@ -299,7 +276,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 const T lhs = cost_value - T(0.5) * gamma * gg + T(0.5) * d2 * inv_gamma;
                 fbe_cur = lhs;
                 fbe_valid = true;
-                if (lhs > rhs_ls && nls < MAX_LS) {
+                if (anyb(lhs > rhs_ls) && nls < MAX_LS) {
                     tau *= T(0.5);
                     nls++;
                     continue;
@@ -350,7 +327,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             const T ip = I.dot2(gv, gw, fv, fw);
             const T rhs = cost_value + LIP_EPS_UPD * tabs(cost_value) - ip +
                           (GAMMA_L * T(0.5) * inv_gamma) * (norm_fpr * norm_fpr);
-            if (cost_half > rhs && lip_it < MAX_LIP && L < MAX_L) {
+            if (anyb(cost_half > rhs && L < MAX_L) && lip_it < MAX_LIP) {
                 // gamma is halved: the speculative candidates (if any) are void, continue sequentially
                 lb_active = 0;
                 lb_first = true;
@@ -417,11 +394,11 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             const bool c2 = n2 == 0 || f2n_plus <= kc->delta_tol + SMALL;
             const bool c3 = akkt_tol <= kc->tol + SMALL;
             bool finished = false, converged = false, out_of_time = false;
-            if (c1 && c2 && c3 && (!single || status == 0)) {
+            if (anyb(c1 && c2 && c3) && (!single || status == 0)) {
                 finished = converged = true;
             } else {
-                const bool stall = alm_iter == 0 || ((dyn_plus <= kc->suff_dec * dyn + SMALL) &&
-                                                     (n2 == 0 || f2n_plus <= kc->suff_dec * f2n + SMALL));
+                const bool stall = alm_iter == 0 || anyb((dyn_plus <= kc->suff_dec * dyn + SMALL) &&
+                                                         (n2 == 0 || f2n_plus <= kc->suff_dec * f2n + SMALL));
                 if (!stall) {
                     c *= kc->pen_update;
                     inv_cdiv = T(1) / (c > T(1) ? c : T(1));
@@ -447,11 +424,13 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                     int ri = inst;
                     asm volatile("" : "+s"(ri));
                     if (lead) {
-                        kc->U[(size_t)ri * 2 * N + 2 * I.k] = uv;
-                        kc->U[(size_t)ri * 2 * N + 2 * I.k + 1] = uw;
+                        int ko = I.k; // (opaque: the lane's offsets are formed here, not hoisted out of the solve and spilled)
+                        asm volatile("" : "+v"(ko));
+                        kc->U[(size_t)ri * 2 * N + 2 * ko] = uv;
+                        kc->U[(size_t)ri * 2 * N + 2 * ko + 1] = uw;
                         if (kc->y) {
-                            kc->y[(size_t)ri * 2 * N + I.k] = yv;
-                            kc->y[(size_t)ri * 2 * N + N + I.k] = yw;
+                            kc->y[(size_t)ri * 2 * N + ko] = yv;
+                            kc->y[(size_t)ri * 2 * N + N + ko] = yw;
                         }
                     }
                     if (I.lane == 0) {
@@ -543,7 +522,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             norm_fpr = tsqrt(ff);
             const auto* kc = cold_args<T>();
             const T akkt = kc->akkt_form ? tsqrt(aa) * inv_gamma : tsqrt(aa); // (nmpc_config.akkt_form)
-            if (norm_fpr < kc->tol && akkt < akkt_tol) {
+            if (anyb(norm_fpr < kc->tol && akkt < akkt_tol)) {
                 inner_exit = true;
             } else {
                 lip_it = 0;
@@ -591,6 +570,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 const T rhs_c = cbfgs_eps * (cbfgs_alpha == T(1) ? norm_fpr : tpow(norm_fpr, cbfgs_alpha));
                 ok = lhs > rhs_c && tfinite(lhs) && tfinite(rhs_c);
             }
+            ok = anyb(ok);
             if (ok) {
                 osv = uv;
                 osw = uw;
@@ -598,7 +578,11 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 ogw = fw;
                 lb_head = lb_head == 0 ? mem - 1 : lb_head - 1;
                 // all wavefronts write the same values to the same addresses
-                if (lead) hist[lb_head * N + I.k] = Quad<T>{nsv, nsw, nyv, nyw};
+                if (lead) {
+                    int ko = I.k; // (opaque, as above)
+                    asm volatile("" : "+v"(ko));
+                    hist[lb_head * N + ko] = Quad<T>{nsv, nsw, nyv, nyw};
+                }
                 rho.set(lb_head, T(1) / ys);
                 lb_gamma = ys / I.dot2(nyv, nyw, nyv, nyw);
                 lb_active = lb_active + 1 < mem ? lb_active + 1 : mem;
