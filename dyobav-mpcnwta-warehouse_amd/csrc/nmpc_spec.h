@@ -38,6 +38,15 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     const T GAMMA_L = T(0.95), LIP_EPS_UPD = T(1e-6), MIN_L = T(1e-10), MAX_L = T(1e9);
     const int MAX_LIP = 10, MAX_LS = 10;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // ROLES (round 4). One wavefront of the workgroup -- the master, role 0 -- runs the solver; the others are workers
+    // that evaluate the line-search candidates it hands them and sleep at a barrier in between. (Rounds 2-3: every
+    // wavefront ran the whole state machine on identical data and replayed the acceptance logic itself -- W copies of
+    // the two-loop recursion, the L-BFGS update, the step head: half of a workgroup's instructions, issued W times. A
+    // batch that oversubscribes the SIMDs pays for them with the critical path of every other instance.) The master is
+    // wavefront inst % W, so that the always-busy wavefronts of co-resident workgroups do not pile up on one SIMD.
+    int role = wave - inst % W;
+    if (role < 0) role += W;
+    role = __builtin_amdgcn_readfirstlane(role);
 
     Instance<T, LPS, GLB, RS, false, false, AXIS> I(kp, kp.P + (size_t)inst * kp.np, lds, GLB ? kp.ws + (long long)inst * kp.ws_stride : nullptr);
     if (const int bad = I.load()) { // NMPC_CAPACITY_EXCEEDED / NMPC_NOT_AXIS_ALIGNED (uniform over the workgroup)
@@ -109,8 +118,15 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     // the LPS lanes of a step hold copies of the step's scalars that may differ in the last bit (each lane's
     // suffix sum associates differently), and every lane must get exactly what it would have computed itself.
     const int XS = 2 * 64 + 4;
-    T* xch = lds + kp.lds_xch;
-    int xbuf = 0;
+    T* xch = lds + kp.lds_xch;    // results: one row per role
+    // commands of the master: y (2 x 64), then (ev, ew) of roles 1..W-1 (2 x 64 each), then the scalars ec, 1/max(c,1) and
+    // two ints: bit r = role r evaluates, exit flag. (Addresses formed where they are used, from an opaque W: kept in
+    // scalar registers for the whole solve they displaced solver state into v_writelane / v_readlane traffic.)
+    auto cmd_area = [&]() {
+        int Wv = W;
+        asm volatile("" : "+s"(Wv));
+        return xch + Wv * XS;
+    };
 
     const T vlo = kp.vmin, vhi = kp.vmax, wlo = -kp.wmax, whi = kp.wmax;
     auto project = [&](T& a, T& b) {
@@ -198,19 +214,42 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         do_eval = true;
         exchange = false;
     };
-    // line-search candidates nls, nls+1, ... on wavefronts first, first+1, ... (tau is the candidate nls's step)
-    auto request_candidates = [&](int first, int wv) {
+    // line-search candidates nls, nls+1, ... for roles first, first+1, ... (tau is the candidate nls's step): the master's
+    // own request, the workers' through the command area, then the barrier the workers wait at
+    auto request_candidates = [&](int first) {
         exchange = true;
-        if (wv >= first) {
-            const int off = wv - first;
-            T tw = tau;
-            for (int i = 0; i < off; ++i) tw *= T(0.5);
-            do_eval = nls + off <= MAX_LS; // candidate MAX_LS is accepted unconditionally, nothing lies beyond it
-            ev = ls_point(uv, fv, dv, tw);
-            ew = ls_point(uw, fw, dw, tw);
+        if (first == 0) {
+            do_eval = nls <= MAX_LS; // candidate MAX_LS is accepted unconditionally, nothing lies beyond it
+            ev = ls_point(uv, fv, dv, tau);
+            ew = ls_point(uw, fw, dw, tau);
             ec = c;
             want_grad = true;
         }
+        T* const cmd = cmd_area();
+        T* const cmds = cmd + 2 * 64 * W;
+        T tw = tau;
+        int flags = 0;
+        for (int r = 1; r < W; ++r) {
+            if (r > first) tw *= T(0.5);
+            cmd[2 * 64 * r + I.lane] = ls_point(uv, fv, dv, tw);
+            cmd[2 * 64 * r + 64 + I.lane] = ls_point(uw, fw, dw, tw);
+            if (nls + (r - first) <= MAX_LS) flags |= 1 << r;
+        }
+        cmd[I.lane] = yv;
+        cmd[64 + I.lane] = yw;
+        if (I.lane == 0) {
+            cmds[0] = c;
+            cmds[1] = inv_cdiv;
+            reinterpret_cast<int*>(cmds + 2)[0] = flags;
+            reinterpret_cast<int*>(cmds + 2)[1] = 0;
+        }
+        __syncthreads(); // (A) the workers start
+    };
+    // the master is done (finished, or parked at the stage boundary): release the workers
+    auto dismiss_workers = [&]() {
+        T* const cmds = cmd_area() + 2 * 64 * W;
+        if (I.lane == 0) reinterpret_cast<int*>(cmds + 2)[1] = 1;
+        __syncthreads();
     };
 
     // The integer / boolean solver state is the same in every lane by construction; the tests on floating-point values
@@ -221,8 +260,23 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     for (;;) {
         // wavefront index / budget flag as opaque per-round values: conditions on them are then evaluated where they
         // are used (s_cmp) instead of living in SGPR pairs as loop-invariant lane masks for the whole solve
-        int wv = wave, timed = timed_;
+        int wv = role, timed = timed_;
         asm volatile("" : "+s"(wv), "+s"(timed));
+        if (wv != 0) { // worker: sleep until the master has published a round, take this role's request
+            __syncthreads(); // (A)
+            const T* const cmd = cmd_area();
+            const T* const cmds = cmd + 2 * 64 * W;
+            if (__builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(cmds + 2)[1]) != 0) return;
+            do_eval = (__builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(cmds + 2)[0]) >> wv) & 1;
+            ev = cmd[2 * 64 * wv + I.lane];
+            ew = cmd[2 * 64 * wv + 64 + I.lane];
+            yv = cmd[I.lane];
+            yw = cmd[64 + I.lane];
+            ec = c = cmds[0];
+            inv_cdiv = cmds[1];
+            want_grad = 1;
+            exchange = 1;
+        }
         const T e_icd = ec == c ? inv_cdiv : T(1);
         if (do_eval) {
             if (kSpecPark) park();
@@ -236,9 +290,9 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             if (kSpecPark) unpark();
         }
         NMPC_STAMP(I, 7); // (eval epilogue)
-        const T* xr = xch + xbuf * (W * XS); // results of this round, one row per wavefront
+        const T* xr = xch; // results of this round, one row per role
         if (exchange) {
-            T* xw = xch + xbuf * (W * XS) + wv * XS;
+            T* xw = xch + wv * XS;
             if (do_eval) {
                 if (want_grad) {
                     xw[2 * I.lane] = r_gv;
@@ -246,17 +300,16 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 }
                 if (I.lane == 0) xw[2 * 64] = r_psi;
             }
-            if (timed && wv == 0 && I.lane == 0) {
+            __syncthreads(); // (B) the round's results are in; the workers go back to (A), which also keeps them from
+                             //     overwriting these rows before the master has replayed the round
+            if (timed) { // the clock is read once per exchange round, as before
                 long long el = (long long)__builtin_amdgcn_s_memrealtime() - t_start;
                 if (el > 0x7fffffffll) el = 0x7fffffffll;
-                *reinterpret_cast<int*>(xw + 2 * 64 + 1) = (int)el;
+                t_now = (int)el;
             }
-            __syncthreads();
-            if (timed)
-                t_now = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(xr + 2 * 64 + 1));
-            xbuf ^= 1; // the next round writes the other buffer: no second barrier needed
             rounds++;
         }
+        if (wv != 0) continue;
         NMPC_STAMP(I, 8); // exchange: LDS writes + barrier (= waiting for the slowest wavefront of the round)
 
         // sequential line-search logic replayed on the exchanged results of wavefronts first..W-1
@@ -350,7 +403,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 if (process_candidates(1)) {
                     step_done = true;
                 } else {
-                    request_candidates(0, wv);
+                    request_candidates(0);
                     phase = SP_LSN;
                     continue;
                 }
@@ -370,7 +423,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             if (process_candidates(0)) {
                 step_done = true;
             } else {
-                request_candidates(0, wv);
+                request_candidates(0);
                 continue; // stay in SP_LSN
             }
         } else { // SP_OUTER
@@ -420,7 +473,8 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 if (!converged) status = (out_of_time || !cont_time) ? 2 : 1;
                 bool finite = tfinite(uv) && tfinite(uw) && tfinite(f_u);
                 if (__ballot(!finite) != 0ull) status = 3;
-                if (wv == 0) {
+                dismiss_workers();
+                {
                     int ri = inst;
                     asm volatile("" : "+s"(ri));
                     if (lead) {
@@ -460,8 +514,9 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             }
             {
                 const int cap = kc->stage_outer_cap;
-                if (cap > 0 && outer >= cap) { // park the instance here (KParams::resume); wavefront 0 writes
-                    if (wv == 0) {
+                if (cap > 0 && outer >= cap) { // park the instance here (KParams::resume); the master writes
+                    dismiss_workers();
+                    {
                         int ri = inst;
                         asm volatile("" : "+s"(ri));
                         T* rs = kc->resume + (size_t)ri * kResumeStride;
@@ -577,7 +632,6 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 ogv = fv;
                 ogw = fw;
                 lb_head = lb_head == 0 ? mem - 1 : lb_head - 1;
-                // all wavefronts write the same values to the same addresses
                 if (lead) {
                     int ko = I.k; // (opaque, as above)
                     asm volatile("" : "+v"(ko));
@@ -586,7 +640,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 rho.set(lb_head, T(1) / ys);
                 lb_gamma = ys / I.dot2(nyv, nyw, nyv, nyw);
                 lb_active = lb_active + 1 < mem ? lb_active + 1 : mem;
-                __syncthreads();
+                // (no barrier: the master alone writes and reads the ring, and a wavefront's LDS accesses stay in order)
             }
         }
         NMPC_STAMP(I, 12); // L-BFGS update
@@ -609,17 +663,16 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         tau = 1;
         nls = 0;
         if (spec) {
-            request_candidates(1, wv); // wavefronts 1.. : candidates 0..W-2
-            if (wv == 0) {         // wavefront 0: the Lipschitz test's psi(u_half)
-                ev = hv;
-                ew = hw;
-                ec = c;
-                want_grad = false;
-                do_eval = true;
-            }
+            // the master: the Lipschitz test's psi(u_half); roles 1.. : candidates 0..W-2
+            ev = hv;
+            ew = hw;
+            ec = c;
+            want_grad = false;
+            do_eval = true;
+            request_candidates(1);
             phase = SP_SPEC0;
         } else {
-            request_candidates(0, wv);
+            request_candidates(0);
             phase = SP_LSN;
         }
     }

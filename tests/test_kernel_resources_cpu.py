@@ -55,7 +55,10 @@ def test_fp32_latency_and_cooperative_kernels_spill_little(resources):
     for name, r in _sel(resources, r"^solve_spec_kernel<float").items():
         general = re.search(r"<float, 3, false, (4|14), 2>", name) is not None
         axis = re.search(r"<float, 3, false, (4|14), 1>", name) is not None
-        assert r["sgpr_spill"] <= 24, (name, r)
+        # (round 4: the solver's integer state stays in scalar registers all the way round the loop -- no v_readfirstlane per
+        #  variable and evaluation any more -- and the master / worker split added the command addresses: ~30 SGPRs take
+        #  the v_writelane / v_readlane route, outside the evaluation; measured +6.5 % and +5.8 % on configs[1] all the same)
+        assert r["sgpr_spill"] <= 36, (name, r)
         # (general path of the register-table variants: ~16 VGPRs in scratch; the axis-aligned 4-slot member: 2)
         assert r["scratch"] <= (72 if general else 16 if axis else 0), (name, r)
     sel = _sel(resources, r"solve_coop(_reg)?_kernel<(float|true|false)")
