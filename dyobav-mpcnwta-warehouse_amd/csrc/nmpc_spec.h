@@ -6,18 +6,24 @@
 // (measured on configs[1]: 3.8 candidates per iteration on average, 4.9 for the slowest instances) -- while three
 // quarters of the chip idle once the easy instances have finished.
 //
-// Here a workgroup of W wavefronts owns one instance. All of them run the same solver state machine on the same data
-// (same instructions, same operands => bit-identical state in every wavefront; the tables in LDS are shared), and only
-// the evaluation requests differ: in the first round of an iteration wavefront 0 evaluates psi at the half step (the
-// Lipschitz test) while wavefronts 1..W-1 already evaluate the first W-1 line-search candidates, computed under the
-// assumption that the test passes (it does unless gamma has to be halved, which resets the L-BFGS buffer anyway);
-// later rounds evaluate W candidates at a time. Results (psi, gradient) are exchanged through a double-buffered LDS
-// area, one s_barrier per round, and every wavefront then replays the sequential acceptance logic on them in order.
-// Each candidate is the same function of the same inputs as in the sequential order, the acceptance tests run in the
-// same order on the same numbers, so the results do not depend on W: launched with one wavefront this kernel IS the
-// sequential algorithm, and 2, 3 or 4 wavefronts give BIT-IDENTICAL results (tested); evaluations whose results are
-// never looked at are the price (info[6] = exchange rounds, info[7] = W). solve_instance() -- the throughput kernel
-// for large batches -- is a separate compilation of the same algorithm and agrees with this one to rounding only.
+// Here a workgroup of W wavefronts owns one instance. One of them -- the MASTER, role 0 -- runs the solver state machine;
+// the others are WORKERS that evaluate the line-search candidates the master hands them (the tables in LDS are shared,
+// every wavefront keeps its own copy of the register-resident obstacle rows) and sleep at a barrier in between. In the
+// first round of an iteration the master evaluates psi at the half step (the Lipschitz test) while roles 1..W-1 already
+// evaluate the first W-1 line-search candidates, computed under the assumption that the test passes (it does unless
+// gamma has to be halved, which resets the L-BFGS buffer anyway); later rounds evaluate W candidates at a time. A round:
+// the master writes every role's request to the command area, barrier (A), everybody evaluates (ONE evaluation site in
+// the code, so every candidate goes through the same instructions whoever takes it), results (psi, gradient) to the
+// result rows, barrier (B), the master replays the sequential acceptance logic on them in order. Each candidate is the
+// same function of the same inputs as in the sequential order, the acceptance tests run in the same order on the same
+// numbers, so the results do not depend on W: launched with one wavefront this kernel IS the sequential algorithm, and
+// 2, 3 or 4 wavefronts give BIT-IDENTICAL results (tested); evaluations whose results are never looked at are the price
+// (info[6] = exchange rounds, info[7] = W). solve_instance() -- the throughput kernel for large batches -- is a separate
+// compilation of the same algorithm and agrees with this one to rounding only.
+// (Rounds 2-3 ran the whole state machine in every wavefront on identical data -- W copies of the two-loop recursion, the
+//  L-BFGS update and the step head per iteration, about half of a workgroup's instructions issued W times over. With the
+//  roles configs[1] went from 44.8 to 47.4 k solves/s, same bits. What bounds that batch now is the serial chain of its
+//  slowest instance: B = 64 ... 1024 all take 18-23 ms, profiles/r04_exp_cfg1_batch_size_and_up_to_8_wavefronts.txt.)
 //
 // Restates the same OpEn pieces as solve_instance (core::panoc, lbfgs, alm); see the notes there.
 #pragma once
