@@ -94,7 +94,10 @@ struct Layout {
 #ifndef NMPC_SPEC_WPE_F32
 #define NMPC_SPEC_WPE_F32 3 // wavefronts per SIMD the fp32 latency kernel is compiled for (caps VGPRs at 168)
 #endif
-constexpr int kSpecWaves = 4; // wavefronts per instance in latency mode (nmpc_spec.h)
+constexpr int kSpecWaves = 4; // wavefronts per instance in latency mode (nmpc_spec.h): automatic choice for batches up to one
+                              // workgroup per SIMD; wavefronts of the cooperative kernels
+constexpr int kSpecWavesWide = 6; // ... for batches of at most one workgroup per CU (the master + five workers: LIP + 5 candidates a round)
+constexpr int kSpecWavesMax = 8;  // most that nmpc_config.latency_waves may ask for
 constexpr size_t kLdsLimit = 160 * 1024; // bytes of LDS one workgroup may use on gfx950
 
 int round4(int x) { return (x + 3) & ~3; }
@@ -175,7 +178,7 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false,
     // latency kernel: one parking area per wavefront (register-table variants only), then the exchange area:
     // 2 buffers x kSpecWaves x (64 lanes x 2 gradient entries + psi)
     L.lds_xch = L.lds_park + (L.rs ? kSpecWaves * park_one : 0);
-    L.lds_total_spec = L.lds_xch + 2 * kSpecWaves * (2 * 64 + 4);
+    L.lds_total_spec = L.lds_xch + 2 * kSpecWavesMax * (2 * 64 + 4);
     const int cw = coop_rs ? kCoopRegWaves : kSpecWaves;
     L.lds_xch_coop = L.lds_park + 2 * park_one; // cooperative kernels: two shared parking areas, used alternately
     L.lds_total_coop = L.lds_xch_coop + 2 * cw * nmpc::kCoopXchStride;
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(64 * kCoopRegWaves, 2) void solve_coop_reg_kernel(n
 
 // latency mode: kSpecWaves wavefronts per instance, speculative line search (nmpc_spec.h)
 template <typename T, int LPS, bool GLB, int RS = 0, int ONLY = 0>
-__global__ __launch_bounds__(64 * kSpecWaves, (wpe<T, RS>(NMPC_SPEC_WPE_F32))) void solve_spec_kernel(nmpc::KParams<T> kp)
+__global__ __launch_bounds__(64 * kSpecWavesMax, (wpe<T, RS>(NMPC_SPEC_WPE_F32))) void solve_spec_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if constexpr (kHasAxisVariant<T, LPS, RS> && !GLB) {
@@ -791,6 +794,12 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
         // ones and the faster line search of the long ones wins: 41.8 k (W = 4) against 40.0 k (W = 3) and 35.4 k (W = 2),
         // `passing` 46.6 / 41.8 / 34.7 k -- profiles/r04_exp_cfg1_waves.txt. Results do not depend on W, bit for bit.)
         lw = B <= cap ? (sizeof(T) == 4 ? (L.rs >= kRegSlotsLarge ? 2 : kSpecWaves) : kSpecWaves) : B <= 4 * cap ? 2 : 1;
+        // At most one workgroup per CU (what a fleet's real-time loop sends: a handful of robots): six wavefronts -- the master
+        // and five workers, the Lipschitz evaluation + five candidates in the first round of an iteration (1.3 instead of 1.6-1.8
+        // rounds per iteration on the long instances). B = 64 / 256: 23.4 -> 21.8 / 18.5 -> 17.3 ms; from two workgroups per CU
+        // on (B = 512) six or eight wavefronts cost more than they bring
+        // (profiles/r04_exp_cfg1_batch_size_and_up_to_8_wavefronts.txt). Same results, bit for bit.
+        if (sizeof(T) == 4 && L.rs < kRegSlotsLarge && !L.glb && 4 * B <= h->n_simd) lw = kSpecWavesWide;
         // Large batches whose LDS tables allow only a few workgroups per CU (e.g. 40 active obstacle rows: 35 KB,
         // 4 per CU = one wavefront per SIMD): the wavefronts of a latency-kernel workgroup SHARE the instance's
         // tables, so W of them fill the SIMDs that the throughput kernel leaves empty (measured on configs[2]:
@@ -815,7 +824,7 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
             }
         }
     }
-    int waves = lw == 1 ? 0 : lw < 0 ? 1 : lw > kSpecWaves ? kSpecWaves : lw;
+    int waves = lw == 1 ? 0 : lw < 0 ? 1 : lw > kSpecWavesMax ? kSpecWavesMax : lw;
     if (!h->spec_ok[sizeof(T) == 4 ? 0 : 1]) waves = 0;
     // cooperative evaluation (nmpc_config.coop_waves): explicit request, or automatic where the obstacle table is streamed
     // from global memory (configs[4]: the obstacle loop is 94 % of the time and its rows split cleanly over the

@@ -34,7 +34,7 @@ def test_latency_mode_is_bit_identical(dtype, kw):
     P = nm.scenarios.make_batch(96, **kw)
     cfg = nm.default_config_struct()
     a = _solve(cfg, P, dtype, -1)
-    for waves in (2, 3, 4):
+    for waves in (2, 3, 4, 6, 8):                                    # (6: what batches of at most one workgroup per CU get)
         b = _solve(cfg, P, dtype, waves)
         _same(a, b)
         assert (b["info"][:, 7] == waves).all()
@@ -72,18 +72,24 @@ def test_latency_mode_other_dimensions():
 
 
 def test_automatic_choice_follows_batch_size():
-    """latency_waves = 0: small batches get four wavefronts per instance (round 4: with the long instances started first
-    the faster line search wins over what stays resident together; 2 with the 14-slot register table, whose kernels run
-    two wavefronts per SIMD), mid-size batches 2, large ones the throughput kernel (info[7] = wavefronts per instance,
-    0 = throughput kernel)."""
+    """latency_waves = 0: batches of at most one workgroup per CU get six wavefronts per instance (fp32, 4-slot register
+    table), small batches four (round 4: with the long instances started first the faster line search wins over what stays
+    resident together; 2 with the 14-slot register table, whose kernels run two wavefronts per SIMD), mid-size batches 2,
+    large ones the throughput kernel (info[7] = wavefronts per instance, 0 = throughput kernel)."""
     P_small = nm.scenarios.make_batch(32, seed=37)
-    for hint, dtype, expect in ((10, np.float32, 4), (0, np.float32, 2), (0, np.float64, 4)):
+    for hint, dtype, expect in ((10, np.float32, 6), (0, np.float32, 2), (0, np.float64, 4)):
         cfg = nm.default_config_struct()
         cfg.latency_waves = 0
         cfg.max_active_dynobs = hint
         with nm.Handle(cfg) as h:
             small = h.solve(P_small.astype(dtype), dtype=dtype)
         assert (small["info"][:, 7] == expect).all(), (hint, dtype, small["info"][0, 7])
+    cfg = nm.default_config_struct()
+    cfg.latency_waves = 0
+    cfg.max_active_dynobs = 10
+    with nm.Handle(cfg) as h:                                          # more than one workgroup per CU, at most one per SIMD
+        four = h.solve(nm.scenarios.make_batch(600, seed=37).astype(np.float32), dtype=np.float32)
+    assert (four["info"][:, 7] == 4).all(), four["info"][0, 7]
     cfg = nm.default_config_struct()
     cfg.latency_waves = 0
     h = nm.Handle(cfg)

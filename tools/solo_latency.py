@@ -9,7 +9,7 @@ P = nm.scenarios.make_batch(1024, seed=0).astype(np.float32)
 with nm.Handle(nm.default_config_struct()) as h0:
     top = int(np.argmax(h0.solve(P)["iters"][:, 1]))
 for axis in (0, -1):
-  for w in (1, -1, 2, 3, 4):
+  for w in (1, -1, 2, 3, 4, 6, 8):
     cfg = nm.default_config_struct(); cfg.max_active_dynobs = 10; cfg.latency_waves = w; cfg.axis_aligned = axis
     h = nm.Handle(cfg)
     for _ in range(2):
