@@ -15,7 +15,7 @@ from . import build as _build
 
 EXIT_STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotFiniteComputation",
                      "CapacityExceeded", "NotAxisAligned")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class NmpcError(RuntimeError):
@@ -75,7 +75,8 @@ class NmpcLoopArgs(C.Structure):
                                            "idx_ref", "goal", "polys", "stagger", "alive", "collision", "complete", "steps",
                                            "clr_dyn", "clr_stc", "dev_sum", "dev_max", "n_traj", "traj", "acts", "state_c",
                                            "last_u_c", "refs_c", "speed_c", "dyn_c", "U_c", "y_c", "U", "y")] +
-                [("gather_y", C.c_int32), ("reserved", C.c_int32)])
+                [("gather_y", C.c_int32), ("n_hyp", C.c_int32)] +
+                [(n, C.c_double) for n in ("hyp_fan_rad", "hyp_radius0", "hyp_radius_growth")])
 
 
 # every symbol include/nmpc_hip.h declares (checked by the CPU test-suite against the built library)

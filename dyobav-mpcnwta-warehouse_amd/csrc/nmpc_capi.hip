@@ -191,7 +191,8 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false,
     L.rs = 0;     // (the GLB kernels index the full [row][t] table: the register-table layout does not apply)
     left_ne = 0;
     ne = cap * (N + 1);
-    L.ws_stride = (long long)(nmpc::kEllStride + 1) * ne;
+    // (room for the general table, 9 values per entry, and for the compressed one: 5 per entry + the expanded t = 0 rows)
+    L.ws_stride = std::max<long long>((long long)(nmpc::kEllStride + 1) * ne, 5LL * ne + 3 + 8LL * cap);
     }
     L.table_entries = ne;
     return L;
@@ -289,13 +290,20 @@ __global__ __launch_bounds__(64, NMPC_WPE_F64) void trace_kernel(nmpc::KParams<d
 }
 
 // cooperative mode: up to kSpecWaves wavefronts per instance share every evaluation (nmpc_device.h, COOP)
-template <typename T, int LPS, bool GLB>
+// GLB: a PAIR like the register-table kernels -- ONLY = 1: the compressed table of axis-aligned ellipses (5 instead of 9
+// values streamed per entry, nmpc_device.h Instance::CMP), ONLY = 2: the general table; the member the launch does not take
+// returns at once (KParams::axis_mode). ONLY = 0: no variants (table in LDS).
+template <typename T, int LPS, bool GLB, int ONLY = 0>
 __global__ __launch_bounds__(64 * kSpecWaves, (sizeof(T) == 4 ? NMPC_SPEC_WPE_F32 : NMPC_WPE_F64)) void solve_coop_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if constexpr (ONLY != 0) {
+        static_assert(GLB, "the compressed table is a variant of the global one");
+        if (nmpc::axis_path(kp) != (ONLY == 1)) return;
+    }
     const int inst = nmpc::dispatch_index(kp);
     if (nmpc::finished_in_pilot<T>(inst)) return;
-    nmpc::solve_instance<T, LPS, GLB, 0, true>(kp, inst, reinterpret_cast<T*>(smem));
+    nmpc::solve_instance<T, LPS, GLB, 0, true, false, ONLY == 1>(kp, inst, reinterpret_cast<T*>(smem));
 }
 // ... with the obstacle table on chip instead of in global memory, for one lane per horizon step (N > 32), where it does
 // not fit LDS: EIGHT wavefronts (two per SIMD) keep 12 rows each in registers, the remaining rows live in LDS
@@ -616,14 +624,16 @@ void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k, const Layout* lay
 // The same evaluation through the cooperative kernels' code path (W wavefronts share it; wavefront 0 writes): what
 // nmpc_eval_batch_* launches when the handle's coop_waves asks for the cooperative mode, so that psi / grad psi of the
 // row split, the partial-sum exchange and the helper lanes can be compared with the oracle directly.
-template <typename T, int LPS, bool GLB, int RS, bool HLP, int WAVES>
+template <typename T, int LPS, bool GLB, int RS, bool HLP, int WAVES, int ONLY = 0>
 __global__ __launch_bounds__(64 * WAVES, (RS > 0 ? 2 : (sizeof(T) == 4 ? NMPC_SPEC_WPE_F32 : NMPC_WPE_F64)))
 void eval_coop_kernel(nmpc::KParams<T> kp, nmpc::EvalParams<T> ep)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if constexpr (ONLY != 0)
+        if (nmpc::axis_path(kp) != (ONLY == 1)) return; // (global table: compressed / general member of the pair)
     const int inst = blockIdx.x, N = kp.N;
     T* lds = reinterpret_cast<T*>(smem);
-    nmpc::Instance<T, LPS, GLB, RS, true, HLP> I(kp, kp.P + (size_t)inst * kp.np, lds,
+    nmpc::Instance<T, LPS, GLB, RS, true, HLP, ONLY == 1> I(kp, kp.P + (size_t)inst * kp.np, lds,
                                                  GLB ? kp.ws + (long long)inst * kp.ws_stride : nullptr);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     I.cw_ = wave;
@@ -696,10 +706,12 @@ SolveFn<T> pick_solve_spec(int lps, bool glb, int rs = 0, int only = 1)
     return lps == 3 ? solve_spec_kernel<T, 3, false> : lps == 2 ? solve_spec_kernel<T, 2, false> : solve_spec_kernel<T, 1, false>;
 }
 
+// (global table: `only` = 1 the compressed-table member of the pair, 2 the general one)
 template <typename T>
-SolveFn<T> pick_solve_coop(int lps, bool glb)
+SolveFn<T> pick_solve_coop(int lps, bool glb, int only = 2)
 {
-    if (glb) return lps == 3 ? solve_coop_kernel<T, 3, true> : lps == 2 ? solve_coop_kernel<T, 2, true> : solve_coop_kernel<T, 1, true>;
+    if (glb && only == 1) return lps == 3 ? solve_coop_kernel<T, 3, true, 1> : lps == 2 ? solve_coop_kernel<T, 2, true, 1> : solve_coop_kernel<T, 1, true, 1>;
+    if (glb) return lps == 3 ? solve_coop_kernel<T, 3, true, 2> : lps == 2 ? solve_coop_kernel<T, 2, true, 2> : solve_coop_kernel<T, 1, true, 2>;
     return lps == 3 ? solve_coop_kernel<T, 3, false> : lps == 2 ? solve_coop_kernel<T, 2, false> : solve_coop_kernel<T, 1, false>;
 }
 
@@ -716,10 +728,11 @@ EvalFn<T> pick_eval(int lps, bool glb, int rs = 0, int only = 1)
 }
 
 template <typename T>
-EvalFn<T> pick_eval_coop(int lps, bool glb)
+EvalFn<T> pick_eval_coop(int lps, bool glb, int only = 2)
 {
     constexpr int W = kSpecWaves;
-    if (glb) return lps == 3 ? eval_coop_kernel<T, 3, true, 0, false, W> : lps == 2 ? eval_coop_kernel<T, 2, true, 0, false, W> : eval_coop_kernel<T, 1, true, 0, false, W>;
+    if (glb && only == 1) return lps == 3 ? eval_coop_kernel<T, 3, true, 0, false, W, 1> : lps == 2 ? eval_coop_kernel<T, 2, true, 0, false, W, 1> : eval_coop_kernel<T, 1, true, 0, false, W, 1>;
+    if (glb) return lps == 3 ? eval_coop_kernel<T, 3, true, 0, false, W, 2> : lps == 2 ? eval_coop_kernel<T, 2, true, 0, false, W, 2> : eval_coop_kernel<T, 1, true, 0, false, W, 2>;
     return lps == 3 ? eval_coop_kernel<T, 3, false, 0, false, W> : lps == 2 ? eval_coop_kernel<T, 2, false, 0, false, W> : eval_coop_kernel<T, 1, false, 0, false, W>;
 }
 EvalFn<float> pick_eval_coop_reg(int N)
@@ -839,9 +852,10 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
     if (pl.has_axis) pl.fn2 = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs, 2) : pick_solve<T>(h->lps, L.glb, L.rs, 2);
     pl.uses_ws = L.glb;
     if (coop > 1) {
-        pl.fn = pick_solve_coop<T>(h->lps, L.glb);
-        pl.fn2 = nullptr;
-        pl.has_axis = false;
+        // global table: the pair (compressed table of axis-aligned ellipses / general table); LDS table: one kernel
+        pl.fn = pick_solve_coop<T>(h->lps, L.glb, L.glb ? 1 : 2);
+        pl.fn2 = L.glb ? pick_solve_coop<T>(h->lps, true, 2) : nullptr;
+        pl.has_axis = L.glb;
         pl.lds_bytes = (size_t)L.lds_total_coop * sizeof(T);
         k.lds_xch = L.lds_xch_coop;
         waves = coop;
@@ -854,6 +868,8 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
                 fill_layout(k, C);
                 k.lds_xch = C.lds_xch_coop;
                 pl.fn = pick_solve_coop_reg(h->cfg.N_hor);
+                pl.fn2 = nullptr;
+                pl.has_axis = false;
                 pl.lds_bytes = (size_t)C.lds_total_coop * sizeof(T);
                 pl.uses_ws = false;
             }
@@ -1269,9 +1285,9 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
     // coop_waves > 1: evaluate through the cooperative kernels' code path (same variant choice as solve_batch)
     if (h->cfg.coop_waves > 1 && L.rs == 0 && h->coop_ok[sizeof(T) == 4 ? 0 : 1]) {
         waves = std::min<int>(h->cfg.coop_waves, kSpecWaves);
-        fn = pick_eval_coop<T>(h->lps, L.glb);
-        fn2 = nullptr;
-        has_axis = false;
+        fn = pick_eval_coop<T>(h->lps, L.glb, L.glb ? 1 : 2);
+        fn2 = L.glb ? pick_eval_coop<T>(h->lps, true, 2) : nullptr;
+        has_axis = L.glb;
         lds_bytes = (size_t)L.lds_total_coop * sizeof(T);
         k.lds_xch = L.lds_xch_coop;
         if constexpr (sizeof(T) == 4) {
@@ -1281,6 +1297,8 @@ int eval_batch(nmpc_handle_s* h, const T* P, const T* U, const T* Y, const T* C,
                 k.lds_xch = C.lds_xch_coop;
                 waves = kCoopRegWaves;
                 fn = pick_eval_coop_reg(h->cfg.N_hor);
+                fn2 = nullptr;
+                has_axis = false;
                 lds_bytes = (size_t)C.lds_total_coop * sizeof(T);
                 uses_ws = false;
             }
@@ -1431,6 +1449,8 @@ int loop_step(nmpc_handle_s* h, const nmpc_loop_args* g, bool post)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_loop_*: bad dimensions (B %d, n_run %d, H %d, W %d, Lmax %d, M %d, step %d of %d)",
                     g->B, g->n_run, g->H, g->W, g->Lmax, g->M, g->step, g->max_steps);
     if (!g->run && g->n_run != g->B) return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_loop_*: run = NULL needs n_run = B");
+    if (g->n_hyp < 0 || (g->n_hyp > 1 && (long long)g->H * g->n_hyp > h->cfg.Ndynobs))
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "nmpc_loop_*: H * n_hyp = %d x %d rows exceed Ndynobs = %d", g->H, g->n_hyp, h->cfg.Ndynobs);
     const void* need[] = {g->robot, g->last_u, g->humans, g->hist, g->hcount, g->hidx, g->hpath, g->ref_traj, g->ref_len,
                           g->idx_ref, g->goal, g->alive, g->collision, g->complete, g->steps, g->clr_dyn, g->clr_stc,
                           g->dev_sum, g->dev_max, g->n_traj, g->traj, g->acts, g->state_c, g->last_u_c, g->refs_c,
@@ -1465,6 +1485,7 @@ int loop_step(nmpc_handle_s* h, const nmpc_loop_args* g, bool post)
     p.speed_c = static_cast<T*>(g->speed_c), p.dyn_c = static_cast<T*>(g->dyn_c);
     p.U_c = static_cast<T*>(g->U_c), p.y_c = static_cast<T*>(g->y_c), p.U = static_cast<T*>(g->U), p.y = static_cast<T*>(g->y);
     p.gather_y = g->gather_y;
+    p.n_hyp = g->n_hyp, p.hyp_fan = (T)g->hyp_fan_rad, p.hyp_r0 = (T)g->hyp_radius0, p.hyp_grow = (T)g->hyp_radius_growth;
     if (post)
         hipLaunchKernelGGL(nmpc::loop_post_kernel<T>, dim3(g->n_run), dim3(64), 0, h->stream, p);
     else
@@ -1498,10 +1519,12 @@ int set_lds_limit(nmpc_handle_s* h)
     if (coop_bytes > kLdsLimit) {
         h->coop_ok[sizeof(T) == 4 ? 0 : 1] = false;
     } else if (coop_bytes > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve_coop<T>(h->lps, L.glb)),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_eval_coop<T>(h->lps, L.glb)),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_bytes));
+        for (int only = 1; only <= 2; ++only) { // (global table: both members of the pair; else the same kernel twice)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve_coop<T>(h->lps, L.glb, only)),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_bytes));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_eval_coop<T>(h->lps, L.glb, only)),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_bytes));
+        }
     }
     const size_t spec_bytes = (size_t)L.lds_total_spec * sizeof(T);
     if (spec_bytes > kLdsLimit) {

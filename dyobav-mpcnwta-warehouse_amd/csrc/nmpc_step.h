@@ -52,6 +52,9 @@ struct LoopParams {
     T *U_c, *y_c;         // solver in / out of the running scenarios
     T *U, *y;             // [B][2N] full copies
     int gather_y;         // pre: y_c[a] = y[b]
+    // hypothesis fan (nmpc_loop_args::n_hyp): n_hyp <= 1 = the reference's one row per pedestrian
+    int n_hyp;
+    T hyp_fan, hyp_r0, hyp_grow;
 };
 
 // ---- before the solve -------------------------------------------------------------------------------------------
@@ -63,8 +66,11 @@ __global__ __launch_bounds__(64) void loop_pre_kernel(LoopParams<T> p)
     const int N = p.N, H = p.H;
     const T rx = p.robot[3 * b], ry = p.robot[3 * b + 1], rth = p.robot[3 * b + 2];
     // constant-velocity prediction: mean of the last <= 4 position differences, extrapolated 0..N steps
-    for (int e = lane; e < H * (N + 1); e += 64) {
-        const int h = e / (N + 1), t = e - h * (N + 1);
+    // (n_hyp > 1: each pedestrian fans out into n_hyp rows around that step -- SURVEY.md 8(d) configs[2], nmpc_hip.h)
+    const int nh = p.n_hyp > 1 ? p.n_hyp : 1;
+    for (int e = lane; e < H * nh * (N + 1); e += 64) {
+        const int row_i = e / (N + 1), t = e - row_i * (N + 1);
+        const int h = row_i / nh, j = row_i - h * nh;
         const T* hs = p.hist + ((size_t)b * H + h) * 10;
         long long nd = p.hcount[(size_t)b * H + h] - 1;
         nd = nd < 0 ? 0 : nd > 4 ? 4 : nd;
@@ -77,10 +83,19 @@ __global__ __launch_bounds__(64) void loop_pre_kernel(LoopParams<T> p)
         const T den = T(nd > 1 ? nd : 1);
         vx /= den;
         vy /= den;
-        T* row = p.dyn_c + (((size_t)a * H + h) * (N + 1) + t) * 6;
-        row[0] = p.humans[((size_t)b * H + h) * 2] + vx * T(t);
-        row[1] = p.humans[((size_t)b * H + h) * 2 + 1] + vy * T(t);
-        row[2] = row[3] = t == 0 ? p.human_size : T(1);
+        T* row = p.dyn_c + (((size_t)a * H * nh + row_i) * (N + 1) + t) * 6;
+        if (nh > 1) {
+            T sa, ca;
+            tsincos((T(j) - T(0.5) * T(nh - 1)) * p.hyp_fan, sa, ca);
+            const T wx = ca * vx - sa * vy, wy = sa * vx + ca * vy;
+            row[0] = p.humans[((size_t)b * H + h) * 2] + wx * T(t);
+            row[1] = p.humans[((size_t)b * H + h) * 2 + 1] + wy * T(t);
+            row[2] = row[3] = p.hyp_r0 + p.hyp_grow * T(t);
+        } else {
+            row[0] = p.humans[((size_t)b * H + h) * 2] + vx * T(t);
+            row[1] = p.humans[((size_t)b * H + h) * 2 + 1] + vy * T(t);
+            row[2] = row[3] = t == 0 ? p.human_size : T(1);
+        }
         row[4] = 0;
         row[5] = 1;
     }

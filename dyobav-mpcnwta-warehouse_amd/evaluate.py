@@ -92,7 +92,13 @@ class BatchEvaluator:
                  human_starts: np.ndarray, human_paths: np.ndarray, map_polygons: np.ndarray, dtype=np.float64,
                  human_stagger: float = 0.0, seed: int = 0, mode: str = "work",
                  tuning: Optional[Sequence[float]] = None, lin_vel_max: float = 1.5, warm_start: bool = False,
-                 compact: Optional[bool] = None, fused: bool = True):
+                 compact: Optional[bool] = None, fused: bool = True, n_hyp: int = 1, hyp_fan: float = 0.15,
+                 hyp_radius_growth: float = 0.05):
+        """``n_hyp`` > 1: every pedestrian enters the solver as ``n_hyp`` obstacle rows fanned around its constant-velocity
+        prediction by ``(j - (n_hyp - 1) / 2) * hyp_fan`` rad, radii ``HUMAN_SIZE + hyp_radius_growth * t`` -- the
+        multi-hypothesis obstacle tensor SURVEY.md 8(d) prescribes for BASELINE configs[2] (4 pedestrians x 10
+        hypotheses), here produced closed-loop from the scenarios' own pedestrian motion instead of one-shot. ``n_hyp``
+        = 1 is the reference's constant-velocity predictor (one row per pedestrian, std 1.0)."""
         import torch
         self.torch = torch
         self.fused = fused
@@ -147,6 +153,12 @@ class BatchEvaluator:
         self.goal = T(np.array([p[-1] for p in robot_paths], dtype=float))   # [B,2]
         self.humans = T(human_starts)                              # [B,H,2]
         self.H = self.humans.shape[1]
+        self.n_hyp, self.hyp_fan, self.hyp_grow = max(1, int(n_hyp)), float(hyp_fan), float(hyp_radius_growth)
+        if self.H * self.n_hyp > config.Ndynobs:
+            raise ValueError(f"{self.H} pedestrians x {self.n_hyp} hypotheses exceed Ndynobs = {config.Ndynobs}")
+        # hook for harvesting (scenarios.harvest_closed_loop): called as on_params(kt, idx, Pa) after the parameter
+        # vectors of time step kt have been assembled (idx = running scenarios of the compact batch, None = all)
+        self.on_params = None
         self.hpath = T(human_paths)                                # [B,H,W,2]
         self.hidx = torch.zeros(B, self.H, dtype=torch.long, device=self.dev)
         self.hist = self.humans[:, :, None, :].repeat(1, 1, 5, 1)  # last <= 5 positions, newest last
@@ -195,6 +207,19 @@ class BatchEvaluator:
         mask = (k >= (4 - nd[..., None])).to(self.tdt)[..., None]
         vel = (diffs * mask).sum(dim=2) / nd.clamp(min=1)[..., None].to(self.tdt)
         off = torch.arange(0, N + 1, device=self.dev, dtype=self.tdt)[None, None, :, None]
+        if self.n_hyp > 1:       # hypothesis fan around the constant-velocity step (nmpc_hip.h, nmpc_loop_args::n_hyp)
+            nh = self.n_hyp
+            ang = (torch.arange(nh, device=self.dev, dtype=self.tdt) - 0.5 * (nh - 1)) * self.hyp_fan
+            ca, sa = torch.cos(ang)[None, None, :], torch.sin(ang)[None, None, :]
+            wx = ca * vel[:, :, None, 0] - sa * vel[:, :, None, 1]                 # [B,H,nh]
+            wy = sa * vel[:, :, None, 0] + ca * vel[:, :, None, 1]
+            w = torch.stack([wx, wy], dim=-1).reshape(B, H * nh, 2)
+            cur = self.humans[:, :, None, :].expand(-1, -1, nh, -1).reshape(B, H * nh, 2)
+            rows = torch.zeros(B, H * nh, N + 1, 6, dtype=self.tdt, device=self.dev)
+            rows[..., 0:2] = cur[:, :, None, :] + w[:, :, None, :] * off
+            rows[..., 2:4] = (HUMAN_SIZE + self.hyp_grow * off)
+            rows[..., 5] = 1.0
+            return rows
         rows = torch.zeros(B, H, N + 1, 6, dtype=self.tdt, device=self.dev)
         rows[..., 0:2] = self.humans[:, :, None, :] + vel[:, :, None, :] * off
         rows[..., 2:4] = 1.0
@@ -294,7 +319,7 @@ class BatchEvaluator:
         dev_max = dev_sum.clone()
         n_traj = z(B, fill=1.0)
         state_c, last_u_c, refs_c, speed_c = z(B, 3), z(B, 2), z(B, N, 3), z(B)
-        dyn_c = z(B, H, N + 1, 6)
+        dyn_c = z(B, H * self.n_hyp, N + 1, 6)
         ya_buf = z(B, 2 * N)
         self.hidx = self.hidx.contiguous()
         self.hcount = self.hcount.contiguous()
@@ -306,6 +331,7 @@ class BatchEvaluator:
         a = _capi.NmpcLoopArgs()
         a.B, a.H, a.W, a.Lmax, a.M, a.max_steps = B, H, int(self.hpath.shape[2]), int(self.ref_traj.shape[1]), int(self.polys.shape[0]), max(max_steps, 1)
         a.base_speed, a.lin_vel_max, a.human_size, a.human_vmax = self.base_speed, self.lin_vel_max, HUMAN_SIZE, HUMAN_VMAX
+        a.n_hyp, a.hyp_fan_rad, a.hyp_radius0, a.hyp_radius_growth = self.n_hyp, self.hyp_fan, HUMAN_SIZE, self.hyp_grow
         for name, t in (("robot", self.robot), ("last_u", last_u), ("humans", self.humans), ("hist", self.hist), ("hcount", self.hcount),
                         ("hidx", self.hidx), ("hpath", self.hpath), ("ref_traj", self.ref_traj), ("ref_len", ref_len),
                         ("idx_ref", self.idx_ref), ("goal", self.goal), ("polys", self.polys), ("alive", alive),
@@ -341,6 +367,8 @@ class BatchEvaluator:
             self.h.loop_step(self.dt, a, post=False)
             self.h.assemble_params(self.dt, nA, Pa, last_u_c, state_c, refs_c, speed_c, self.tuning, self.stcw, self.dynw,
                                    self.polys, dyn_c[:nA])
+            if self.on_params is not None:
+                self.on_params(kt, idx, Pa)
             if record is not None:
                 rec = dict(robot=self.robot.cpu().numpy(), humans=self.humans.cpu().numpy(), alive=alive.bool().cpu().numpy(),
                            y_in=self.y.cpu().numpy())
@@ -425,6 +453,8 @@ class BatchEvaluator:
             ya = self.y if full else self.y.index_select(0, idx).contiguous()
             self.h.assemble_params(self.dt, nA, Pa, sel(last_u), sel(self.robot), sel(refs), sel(speed),
                                    self.tuning, self.stcw, self.dynw, self.polys, sel(dyn))
+            if self.on_params is not None:
+                self.on_params(kt, idx, Pa)
             if record is not None:
                 rec = dict(robot=self.robot.cpu().numpy(), humans=self.humans.cpu().numpy(), alive=alive.cpu().numpy(),
                            y_in=self.y.cpu().numpy())

@@ -227,3 +227,81 @@ def make_config_batch(name: str, B: int | None = None, seed: int | None = None, 
         cfg["seed"] = seed
     layout = cfg.pop("layout")
     return layout, make_batch(layout=layout, dtype=dtype, **cfg)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Closed-loop scenarios: the inputs of evaluate.BatchEvaluator (row f3) for B Monte-Carlo warehouse runs, and the
+# parameter batches harvested from them -- the distribution the reference's own evaluation loop produces
+# (main_eva.py:6-14 -> MainBase.run, main_base.py:448-464: max_num_run repetitions of a scenario with staggering
+# pedestrians; main_base.py:293-302: the obstacle tensor of every time step), as opposed to make_batch's one-shot draw.
+# ---------------------------------------------------------------------------------------------------------------------
+def make_closed_loop_scenarios(B: int, seed: int = 13, n_ped: int = 4, n_boxes: int = 14) -> dict:
+    """B corridor scenarios in the style of the reference's ``scenario_0..2`` (main_base.py:38-57: a robot driving an
+    aisle, pedestrians crossing it on way-point paths): the robot starts near the origin heading along +x towards a goal
+    ~8 m ahead, ``n_boxes`` shelf blocks line the aisle on both sides, ``n_ped`` pedestrians start 5-10 m ahead on
+    either side and walk two way-points across / against the aisle (HUMAN_VMAX with the seeded stagger of
+    basic_agent.py:64-82 is applied by the evaluator). Deterministic in (B, seed, n_ped, n_boxes); returns the keyword
+    arguments of ``BatchEvaluator`` as numpy arrays / lists."""
+    rng = np.random.default_rng(seed)
+    boxes = []
+    for i in range(n_boxes):
+        c = np.array([1.5 + 1.1 * i, (-1) ** i * rng.uniform(1.6, 2.6)])
+        hx, hy = rng.uniform(0.3, 0.6, 2)
+        boxes.append([[c[0] + hx, c[1] + hy], [c[0] - hx, c[1] + hy], [c[0] - hx, c[1] - hy], [c[0] + hx, c[1] - hy]])
+    starts = np.stack([np.zeros(B), rng.uniform(-0.4, 0.4, B), rng.uniform(-0.3, 0.3, B)], axis=1)
+    goals = np.stack([8.0 + rng.uniform(-0.5, 0.5, B), rng.uniform(-0.5, 0.5, B)], axis=1)
+    paths = [[(float(g[0]), float(g[1]))] for g in goals]
+    hstart = np.empty((B, n_ped, 2))
+    hpath = np.empty((B, n_ped, 2, 2))
+    for h in range(n_ped):
+        side = 1.0 if h % 2 == 0 else -1.0
+        x0 = rng.uniform(5.0, 10.0, B)
+        y0 = side * rng.uniform(2.0, 3.5, B)
+        hstart[:, h] = np.stack([x0, y0], axis=1)
+        # first way-point across the aisle and towards the robot, second further down the aisle on the other side
+        w1 = hstart[:, h] + np.stack([rng.uniform(-3.5, -2.0, B), -side * rng.uniform(4.5, 5.5, B)], axis=1)
+        w2 = w1 + np.stack([rng.uniform(-3.5, -2.0, B), -side * rng.uniform(0.0, 1.0, B)], axis=1)
+        hpath[:, h, 0], hpath[:, h, 1] = w1, w2
+    return dict(robot_starts=starts, robot_paths=paths, human_starts=hstart, human_paths=hpath,
+                map_polygons=np.array(boxes))
+
+
+def harvest_closed_loop(config, B: int, steps=(1, 8, 20), seed: int = 13, n_ped: int = 4, n_hyp: int = 10,
+                        dtype=np.float32, human_stagger: float = 0.2, return_device: bool = False):
+    """Parameter vectors ``P[B, np]`` as the closed loop produces them: ``make_closed_loop_scenarios(B, seed, n_ped)``
+    advanced by ``evaluate.BatchEvaluator`` (row f3, pinned to the reference) with ``n_hyp`` hypotheses per pedestrian
+    fanned around the constant-velocity prediction (``config.Ndynobs`` >= n_ped * n_hyp), and the assembled
+    parameter vector of scenario b captured at time step ``steps[b % len(steps)]`` (early / mid-run / near the goal) --
+    or at the last earlier capture step it was still running. Needs the GPU (the closed loop solves on the device).
+    Returns ``(P, step_of_row)``: numpy arrays, or torch device tensors with ``return_device``."""
+    import copy
+
+    import torch
+
+    from .evaluate import BatchEvaluator
+    steps = tuple(sorted(int(s) for s in steps))
+    sc = make_closed_loop_scenarios(B, seed=seed, n_ped=n_ped)
+    cfg = copy.copy(config)
+    cfg.max_active_dynobs = n_ped * n_hyp
+    ev = BatchEvaluator(cfg, dtype=dtype, human_stagger=human_stagger, seed=seed, n_hyp=n_hyp, **sc)
+    ev.time_solves = False
+    out = torch.zeros(B, ev.h.np_, dtype=ev.tdt, device=ev.dev)
+    step_of = torch.full((B,), -1, dtype=torch.int32, device=ev.dev)
+    ns = len(steps)
+
+    def grab(kt, idx, Pa):
+        if kt not in steps:
+            return
+        i = steps.index(kt)
+        rows = idx if idx is not None else torch.arange(B, device=ev.dev)
+        take = (rows % ns == i) | (step_of[rows] < 0)
+        rsel = rows[take]
+        out[rsel] = Pa[:rows.numel()][take]
+        step_of[rsel] = kt
+
+    ev.on_params = grab
+    ev.run(max_steps=steps[-1] + 1)
+    ev.close()
+    if return_device:
+        return out, step_of
+    return out.cpu().numpy(), step_of.cpu().numpy()

@@ -23,22 +23,34 @@ from accuracy_protocol import run_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("workload,family,n", [("cfg1", "toward_robot", 64), ("cfg1", "passing", 64),
-                                               ("cfg2", "toward_robot", 32), ("cfg2", "passing", 48),
-                                               ("cfg4", "passing", 12)])
-def test_accuracy_protocol(workload, family, n):
-    row = run_case(nm, oracle, workload, family, n=n, nthreads=8, tight=(family == "passing"),
-                   audit=(family == "passing"), audit_max=24 if workload != "cfg4" else 4)
-    print(json.dumps(row))
+# (n: instances at the default tolerance -- the oracle side is 8 threads x seconds; n_tight: the tolerance-1e-8 legs, whose
+#  CPU side runs up to 2000 x 15 iterations per instance, twice: the oracle and its twin)
+@pytest.mark.parametrize("workload,family,n,n_tight", [("cfg1", "toward_robot", 64, 0), ("cfg1", "passing", 128, 64),
+                                                       ("cfg2", "toward_robot", 32, 0), ("cfg2", "passing", 128, 32),
+                                                       ("cfg4", "passing", 16, 8)])
+def test_accuracy_protocol(workload, family, n, n_tight):
+    passing = family == "passing"
+    row = run_case(nm, oracle, workload, family, n=n, nthreads=8, tight=passing, audit=passing,
+                   audit_max=24 if workload != "cfg4" else 4, tight_audit=passing and workload != "cfg4", n_tight=n_tight or None)
+    check_protocol_row(row, workload, passing, n)
+
+
+def check_protocol_row(row, workload, passing, n):
+    """What the protocol establishes, asserted on one row (also used by tests/test_gpu_closed_loop.py on parameter batches
+    harvested from the closed loop; `passing` = a family where a good share of the instances converges)."""
+    print(json.dumps({k: v for k, v in row.items() if not k.startswith("divergence_audit")}))
     a, f = row["hip64_vs_oracle64"], row["hip32_vs_hip64"]
     assert a["same_status_frac"] >= 0.9, a
     # Read against the oracle's own noise floor (the fp64 oracle vs the same oracle with its sums associated differently,
     # same instances): the HIP kernels are statistically no further from the oracle than the oracle is from its twin.
+    # Margins (VERDICT r4): what the 512-instance audit of round 4 supports -- same status within 0.05 of the floor's, the
+    # share below 1e-4 within 0.08 on samples with >= 30 instances converged on both sides (0.1 / 0.2 on smaller ones).
     fl = row["oracle64_vs_reassociated"]
-    assert a["same_status_frac"] >= fl["same_status_frac"] - 0.1, (a, fl)
+    big = min(fl["both_converged"], a["both_converged"]) >= 30
+    assert a["same_status_frac"] >= fl["same_status_frac"] - (0.05 if n >= 64 else 0.1), (a, fl)
     if fl["both_converged"] >= 8 and a["both_converged"] >= 8:      # (a fraction of a handful says nothing)
-        assert a["frac_lt_1e-4_both_converged"] >= fl["frac_lt_1e-4_both_converged"] - 0.2, (a, fl)
-    if family == "passing":
+        assert a["frac_lt_1e-4_both_converged"] >= fl["frac_lt_1e-4_both_converged"] - (0.08 if big else 0.2), (a, fl)
+    if passing:
         # first-divergence audit: every pair that ends > 1e-4 apart (one-wavefront fp64 kernel vs oracle) starts together,
         # drifts apart gradually and shows its first differing decision only after that -- or at a near-tie; exactly what
         # the two CPU implementations do among themselves. A genuine algorithmic difference would fail here.
@@ -48,14 +60,39 @@ def test_accuracy_protocol(workload, family, n):
         assert au["n_unexplained"] == 0, [p for p in au["pairs"] if not p["explained"]]
         assert au["oracle_vs_reassociated"]["n_unexplained"] == 0
         t = row["hip64tp_vs_oracle64"]
-        assert t["same_status_frac"] >= fl["same_status_frac"] - 0.1, (t, fl)
-    if family == "passing":                    # the family where the solver converges
-        t = row["hip64_vs_oracle64_tight"]
-        assert t["same_status_frac"] >= 0.75, t
+        assert t["same_status_frac"] >= fl["same_status_frac"] - (0.05 if n >= 64 else 0.1), (t, fl)
+    if passing:                    # the family where the solver converges
+        # ---- tolerance 1e-8 (Lipschitz step 1e-7 on both sides): every pair that converged on both sides is classified
+        #      from its two end points. Both end points stationary (natural residual certified by BOTH evaluators) ->
+        #      agreement far inside the north star's 1e-4; a pair further apart must have a non-stationary end point
+        #      (penalty escalation: gamma ~ 1 / c) or be a second KKT point with another cost. A tight pair that is neither
+        #      fails the test.
+        t, tf = row["hip64_vs_oracle64_tight"], row["oracle64_vs_reassociated_tight"]
+        k, kf = row["tight_kkt_hip64_vs_oracle64"], row["tight_kkt_oracle64_vs_reassociated"]
+        print("tight:", t, "| twin:", tf)
+        for name, kk in (("hip vs oracle", k), ("oracle vs twin", kf)):
+            print("tight KKT,", name, {q: v for q, v in kk.items() if q != "far_pairs"})
+            for r in kk["far_pairs"]:
+                print("   ", r["instance"], r["kind"], "du %.2e rho %.2e" % (r["abs_du"], r["rho_max"]),
+                      "c %.1e / %.1e f %.6f / %.6f" % (r["a"]["penalty"], r["b"]["penalty"], r["a"]["f"], r["b"]["f"]))
+        assert t["same_status_frac"] >= tf["same_status_frac"] - 0.1 and t["same_status_frac"] >= 0.75, (t, tf)
+        assert k["n_unexplained"] == 0 and kf["n_unexplained"] == 0, (k["far_pairs"], kf["far_pairs"])
+        # the two evaluators agree at every end point (differences relative to |psi|: the gradient there is ~1e-5)
+        assert k["max_grad_rel_diff_hip_vs_oracle"] < 1e-9 and k["max_psi_rel_diff_hip_vs_oracle"] < 1e-11, k
+        if workload != "cfg4":
+            assert k["n_both_kkt"] >= 8 and k["max_abs_du_both_kkt"] < 1e-5, k     # (oracle vs twin: 2e-7)
+            assert all(min(r["a"]["penalty"], r["b"]["penalty"]) >= 1e5 for r in k["far_pairs"] if r["kind"] == "not_kkt"), k["far_pairs"]
+            # the HIP kernels leave no larger a share of the tight pairs > 1e-4 apart than the oracle's twin does (+ 2 pairs)
+            far = lambda q: q["n_pairs"] - q["n_agree"]
+            assert far(k) <= far(kf) + 2, (k, kf)
+            ta = row["divergence_audit_tight"]
+            print("tight audit:", {q: v for q, v in ta.items() if q not in ("pairs", "oracle_vs_reassociated")},
+                  "| oracle vs twin:", {q: v for q, v in ta["oracle_vs_reassociated"].items() if q != "pairs"})
+            assert ta["n_unexplained"] == 0, [p for p in ta["pairs"] if not p["explained"]]
+            assert ta["oracle_vs_reassociated"]["n_unexplained"] == 0
         assert a["both_converged"] >= max(3, n // 8), a
         assert a["median_abs_du_both_converged"] < (1e-6 if workload != "cfg4" else 1e-2), a
-        assert t["both_converged"] >= 3 and t["median_abs_du_both_converged"] < 1e-4, t
-        assert t["frac_lt_1e-4_both_converged"] >= 0.5, t
+        assert t["both_converged"] >= 3 and t["median_abs_du_both_converged"] < (1e-6 if workload != "cfg4" else 1e-4), t
         # fp32 against fp64 at the DEFAULT tolerance is only as close as that tolerance pins u (~1e-3, printed above);
         # with the fp64 continuation of the converged instances (nmpc_config.polish) the headline dtype meets the
         # north star's 1e-4 -- against fp64 + the same continuation and against the fp64 fixed point (tolerance 1e-8)
@@ -63,11 +100,13 @@ def test_accuracy_protocol(workload, family, n):
         pp = row["hip32polish_vs_hip64polish"]
         # (N = 40: twice the lever arm -- the continuation's tolerance shrinks with (20 / N)^3 beyond the reference's horizon,
         #  nmpc_hip.h polish_tolerance; VERDICT r3 item 4: 1e-3 was accepted here in round 3)
-        assert pp["n"] >= (3 if workload != "cfg4" else 2) and pp["median_abs_du"] < 1e-4, pp   # (cfg4: 12 instances, ~5 converge)
+        assert pp["n"] >= 3 and pp["median_abs_du"] < 1e-4, pp
         if workload != "cfg4":
             pt, dt = row["hip32polish_vs_hip64_tight"], row["hip64_vs_hip64_tight"]
             assert pt["n"] >= 5 and pt["median_abs_du"] < 1e-4 and pt["frac_lt_1e-4"] >= 0.7, pt
             assert dt["median_abs_du"] > 3e-4, dt          # (what the default tolerance alone locates, fp64 included)
+            print("all returned instances, fp32 vs fp64:", row["all_returned_hip32_vs_hip64"],
+                  "| with polish:", row["all_returned_hip32polish_vs_hip64polish"])
     else:                                      # contract family: almost nothing converges; the runs must still agree
         assert abs(row["converged_frac"]["hip64"] - row["converged_frac"]["oracle64"]) <= 0.1
         assert np.isfinite(a["median_abs_du_all"])

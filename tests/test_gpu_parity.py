@@ -273,6 +273,56 @@ def test_config4_long_horizon_obstacle_table_streamed_from_global_memory():
     assert np.abs(r["U"] - Uo).max() < 1e-6
 
 
+@pytest.mark.parametrize("axis", [0, 1, -1])
+def test_config4_compressed_global_table(axis):
+    """The COMPRESSED streamed table of the cooperative global-table kernels (round 5; nmpc_device.h Instance::CMP): for
+    axis-aligned ellipses an entry is streamed as (cx, cy, rx, ry) + alpha -- 5 values instead of 9 -- and the inverse squared
+    radii are formed where it is used. psi / grad psi against the oracle (f64 1e-11, the bar of the general table), the
+    iterate path of a short solve, and the pair mechanics: axis_aligned = 0 -> the device-side scan picks the compressed
+    member, -1 -> the general table, 1 -> the promise; a rotated ellipse sends the whole call to the general member (0) or
+    is refused for that instance alone (1: status 5, NaN controls)."""
+    lay = nm.scenarios.ParamLayout(40, 10, 10, 160)
+    P = nm.scenarios.make_batch(12, lay, seed=5, n_ped=8, n_hyp=20, ped_mode="oncoming")
+    pr = oracle.Problem(40, 10, 10, 160)
+    rng = np.random.default_rng(9)
+    U = np.stack([rng.uniform(-0.5, 1.5, (12, 40)), rng.uniform(-0.5, 0.5, (12, 40))], axis=2).reshape(12, 80)
+    Y = rng.normal(size=(12, 80))
+    C = rng.uniform(1, 100, 12)
+    want_axis = {0: 2, 1: 1, -1: 0}[axis]
+    ov = dict(coop_waves=4, latency_waves=1, reg_table=-1, axis_aligned=axis)
+    res = {}
+    with nm.Handle(config_for(pr, **ov)) as h:
+        for dt, rp, rg in ((np.float64, 1e-11, 1e-10), (np.float32, 5e-5, 5e-4)):
+            r = h.eval(P, U, Y, C, dtype=dt)
+            li = h.last_launch_info()
+            assert li["family"] == "cooperative" and li["axis_aligned"] == want_axis, li
+            res[dt] = r
+            for i in range(12):
+                v, g = oracle.psi(pr, U[i], C[i], Y[i], P[i])
+                assert r["psi"][i] == pytest.approx(v, rel=rp)
+                np.testing.assert_allclose(r["grad"][i], g, rtol=0, atol=rg * np.abs(g).max())
+    op = oracle.Options(max_outer=1, max_inner=4, lip_delta=1e-4, lip_eps=1e-4)
+    Uo, ro = oracle.solve_batch(pr, op, P, nthreads=8)
+    cfg = config_for(pr, max_outer_iterations=1, max_inner_iterations=4, lip_delta_f64=1e-4, lip_eps_f64=1e-4, **ov)
+    with nm.Handle(cfg) as h:
+        r = h.solve(P)
+        assert h.last_launch_info()["axis_aligned"] == want_axis
+        assert np.array_equal(r["iters"][:, 1], ro["inner_iters"])
+        assert np.abs(r["U"] - Uo).max() < 1e-6
+        # one rotated ellipse in instance 3
+        Pr = P.copy()
+        Pr[3, lay.od + 6 * (5 * 41 + 7) + 4] = 0.3          # (angle; with rx != ry: a rotated CIRCLE is still axis-aligned)
+        Pr[3, lay.od + 6 * (5 * 41 + 7) + 2] *= 1.5
+        Uor, _ = oracle.solve_batch(pr, op, Pr, nthreads=8)
+        rr = h.solve(Pr)
+        if axis == 1:
+            assert rr["status"][3] == 5 and np.isnan(rr["U"][3]).all()
+            ok = np.arange(12) != 3
+            assert np.array_equal(rr["U"][ok], r["U"][ok])
+        else:
+            assert np.abs(rr["U"] - Uor).max() < 1e-6 and (rr["status"] != 5).all()
+
+
 def test_fp32_vs_fp64_tolerance_sweep_long_horizon():
     """BASELINE configs[4]: fp64 vs fp32 at solver tolerances 1e-3 ... 1e-6 (SURVEY.md 8d configuration 5; device vs
     device, reduced batch). Obstacle-free family: both precisions converge to the same controls, the median distance

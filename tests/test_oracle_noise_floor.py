@@ -102,3 +102,38 @@ def test_the_audit_flags_genuine_algorithmic_differences():
         print(f"{name}: {diverged} of 24 instances end > 1e-4 apart, {flagged} of them flagged by the audit")
         assert diverged >= 4, name
         assert flagged >= 0.6 * diverged, (name, flagged, diverged)
+
+
+def test_tight_tolerance_pairs_are_kkt_points_or_penalty_escalation():
+    """VERDICT r4 "What's weak" 1, CPU half: at tolerance 1e-8 (caps 2000 x 15, Lipschitz step 1e-7) the oracle and its
+    re-associated twin are solved on the same instances and EVERY pair that converged on both sides is classified from its
+    two end points (accuracy_protocol.kkt_classification): the natural residual ||u - Proj_U(u - grad psi(u; c, y))|| of
+    the final inner problem, f, ||F2||, dist_C(F1). Where both end points are stationary (rho <= 1e-2) the two
+    implementations agree far inside the north star's 1e-4; the pairs that end further apart are exactly the ones whose
+    end points are NOT stationary -- penalties of 1e7..1e10, where gamma ~ 1 / c makes the exit test ||gamma fpr|| < tol
+    true anywhere -- or, possibly, distinct local minima with different cost. Nothing is left unexplained."""
+    from accuracy_protocol import LIP_STEP_TIGHT, RHO_KKT, TIGHT, TIGHT_CAPS, kkt_classification, oracle_solve_full
+    lay, P = _batch(48)
+    pr = oracle.Problem()
+    op = oracle.Options(lip_delta=LIP_STEP_TIGHT, lip_eps=LIP_STEP_TIGHT, **TIGHT, **TIGHT_CAPS)
+    idx = np.arange(len(P))
+    Ua, Ya, ra = oracle_solve_full(oracle, pr, op, P, idx, nthreads=8)
+    Ub, Yb, rb = oracle_solve_full(oracle, pr, op, P, idx, nthreads=8, reassoc=True)
+    sa, sb = np.array([r["status"] for r in ra]), np.array([r["status"] for r in rb])
+    ca, cb = np.array([r["penalty"] for r in ra]), np.array([r["penalty"] for r in rb])
+    both = np.nonzero((sa == 0) & (sb == 0))[0]
+    k = kkt_classification(oracle, pr, P, both, (Ub[both], Yb[both], cb[both]), (Ua[both], Ya[both], ca[both]))
+    print({kk: v for kk, v in k.items() if kk != "far_pairs"})
+    for r in k["far_pairs"]:
+        print(r["instance"], r["kind"], "du %.2e" % r["abs_du"], "rho %.2e" % r["rho_max"], "c %.1e / %.1e" % (r["a"]["penalty"], r["b"]["penalty"]),
+              "f %.6f / %.6f" % (r["a"]["f"], r["b"]["f"]))
+    assert k["n_pairs"] >= 12 and k["n_unexplained"] == 0, k["far_pairs"]
+    # the well-posed comparison: both end points certified stationary -> agreement three orders inside the bar
+    assert k["n_both_kkt"] >= 10 and k["max_abs_du_both_kkt"] < 1e-5, k
+    # and a clear gap between the two populations: stationary end points sit at <= 2e-3, escalated ones at >= 0.1
+    # (pairs that agree may be escalated ones too: both runs stopping at the same non-stationary point)
+    if k["n_not_kkt"]:
+        assert k["min_rho_of_not_kkt_pairs"] > 10 * RHO_KKT
+        assert all(min(r["a"]["penalty"], r["b"]["penalty"]) >= 1e6 for r in k["far_pairs"] if r["kind"] == "not_kkt")
+    # every end point is feasible for the hard constraints it converged on (delta = 1e-8)
+    assert all(max(r[s]["f2_inf"], r[s]["dist_C_F1"]) <= 1e-7 for r in k["far_pairs"] for s in ("a", "b"))
