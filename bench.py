@@ -316,6 +316,8 @@ def main(argv=None, env_factory=Env):
                          "2..4 = latency mode")
     ap.add_argument("--reg-table", type=int, default=0, help="nmpc_config.reg_table: 0 = automatic, -1 = LDS / global table")
     ap.add_argument("--coop-waves", type=int, default=0, help="nmpc_config.coop_waves: 0 = automatic, 1 = off, 2..4")
+    ap.add_argument("--axis-aligned", type=int, default=0, help="nmpc_config.axis_aligned: 0 = scan of the batch on the device, "
+                    "1 = promised, -1 = the general kernels (diagnostic: the other member of a kernel pair)")
     args = ap.parse_args(argv)
 
     # stdout must carry exactly ONE JSON line: RCCL / HIP libraries print banners and warnings on fd 1, so keep a
@@ -326,7 +328,7 @@ def main(argv=None, env_factory=Env):
 
     env = env_factory(args)
     m = run_workload(env, args.workload, args.family, args.dtype, args.steps, args.warmup, args.batch,
-                     args.latency_waves, args.reg_table, args.coop_waves)
+                     args.latency_waves, args.reg_table, args.coop_waves, axis_aligned=args.axis_aligned)
     layout, P_host, U, status = m.pop("_host")
     gathered = m.pop("_gathered")
 

@@ -82,6 +82,8 @@ struct Layout {
     int lds_alpha, lds_poly, lds_seg, lds_seginv, lds_fl0, lds_fl, lds_iflag, lds_hist, lds_rho, lds_total;
     int lds_xch, lds_total_spec; // latency mode: exchange area + the other wavefronts' parking areas behind lds_total
     int lds_park;
+    int lds_lbc;          // workspace of the compact-form L-BFGS direction (qtab[N] Quads, R, Y'Y)
+    int coop_lanes, lds_t0c; // cooperative kernels: lanes per plane of the exchange area; t = 0 rows of the compressed global table
     int lds_xch_coop, lds_total_coop; // cooperative mode: two shared parking areas, then the partial-sum exchange area
     int lds_left, lds_left_alpha;     // LDS table of the rows beyond the register-resident ones (cooperative register kernel)
     int dyn_cap;          // obstacle rows provisioned per instance
@@ -101,6 +103,8 @@ constexpr int kSpecWavesMax = 8;  // most that nmpc_config.latency_waves may ask
 constexpr size_t kLdsLimit = 160 * 1024; // bytes of LDS one workgroup may use on gfx950
 
 int round4(int x) { return (x + 3) & ~3; }
+// exchange area of a latency-kernel workgroup of W wavefronts (nmpc_spec.h: xch + command area)
+int spec_xch_elems(int W) { return round4(W * (2 * 64 + 4) + 2 * 64 * W + 4); }
 
 constexpr int kRegSlotsSmall = 4, kRegSlotsLarge = 14; // compiled register-table sizes (rows = 3 x slots)
 constexpr int kRegSlotsCoop = 12; // one lane per step: 8 cooperating wavefronts (2 per SIMD, 256 registers each) x 12 slots in
@@ -172,16 +176,22 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false,
     L.lds_iflag = L.lds_fl + round4(c.Nother);         // int list: robots with a non-zero predicted position
     L.lds_hist = L.lds_iflag + round4(c.Ndynobs);  // int flags / compaction map (an int fits in a T)
     L.lds_rho = L.lds_hist + 4 * nmpc::kMem * N;    // L-BFGS ring: kMem x N x (s_v, s_w, y_v, y_w)
-    L.lds_park = L.lds_rho + round4(2 * nmpc::kMem);   // rho[kMem], alpha[kMem]; then the parking area(s) (16-B aligned)
+    L.lds_lbc = L.lds_rho + round4(2 * nmpc::kMem);    // rho[kMem], alpha[kMem]; then the compact-form workspace (16-B aligned)
+    L.lds_park = L.lds_lbc + round4(nmpc::lbfgs_compact_elems<float>(N)); // then the parking area(s)
     const int park_one = nmpc::kParkQuads * 4 * 64;    // elements per wavefront
     L.lds_total = L.lds_park + park_one;
-    // latency kernel: one parking area per wavefront (register-table variants only), then the exchange area:
-    // 2 buffers x kSpecWaves x (64 lanes x 2 gradient entries + psi)
-    L.lds_xch = L.lds_park + (L.rs ? kSpecWaves * park_one : 0);
-    L.lds_total_spec = L.lds_xch + 2 * kSpecWavesMax * (2 * 64 + 4);
+    // latency kernel: (only in a -DNMPC_SPEC_PARK=1 build, register-table variants: one parking area per wavefront of the
+    // largest workgroup -- ADVICE r4: sized for 4 while up to 8 could run), then the exchange area of W wavefronts (nmpc_spec.h):
+    // W result rows of 64 x 2 gradient entries + psi (padded to 132), the master's command area of 2 x 64 x W + 4 scalars
+    L.lds_xch = L.lds_park + ((NMPC_SPEC_PARK && L.rs) ? kSpecWavesMax * park_one : 0);
+    L.lds_total_spec = L.lds_xch + spec_xch_elems(kSpecWavesMax);
     const int cw = coop_rs ? kCoopRegWaves : kSpecWaves;
     L.lds_xch_coop = L.lds_park + 2 * park_one; // cooperative kernels: two shared parking areas, used alternately
-    L.lds_total_coop = L.lds_xch_coop + 2 * cw * nmpc::kCoopXchStride;
+    // exchange area: 2 buffers x cw wavefronts x 2 planes x coop_lanes Quads. Global-table kernels with one lane per step keep
+    // only the lanes that carry a step (nmpc_device.h) and put the t = 0 rows of the compressed table behind it
+    L.coop_lanes = (L.glb && 64 / N == 1) ? std::min(64, round4(N)) : 64;
+    L.lds_t0c = L.lds_xch_coop + 2 * cw * 2 * 4 * L.coop_lanes;
+    L.lds_total_coop = L.lds_t0c + (L.glb ? round4((nmpc::kEllStride + 1) * cap) : 0);
     if (coop_rs) { // no global fallback for this variant: it either fits LDS or is not offered
         if ((size_t)L.lds_total_coop * elem_size > kLdsLimit) L.rs = 0;
         break;
@@ -192,7 +202,7 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false,
     left_ne = 0;
     ne = cap * (N + 1);
     // (room for the general table, 9 values per entry, and for the compressed one: 5 per entry + the expanded t = 0 rows)
-    L.ws_stride = std::max<long long>((long long)(nmpc::kEllStride + 1) * ne, 5LL * ne + 3 + 8LL * cap);
+    L.ws_stride = (long long)(nmpc::kEllStride + 1) * ne; // (the compressed table -- 5 values per entry -- uses a prefix of it)
     }
     L.table_entries = ne;
     return L;
@@ -576,6 +586,9 @@ void fill_layout(nmpc::KParams<T>& k, const Layout& L)
     k.lds_total = L.lds_total;
     k.lds_xch = L.lds_xch;
     k.lds_park = L.lds_park;
+    k.lds_lbc = L.lds_lbc;
+    k.coop_lanes = L.coop_lanes;
+    k.lds_t0c = L.lds_t0c;
     k.lds_left = L.lds_left;
     k.lds_left_alpha = L.lds_left_alpha;
 }
@@ -812,7 +825,8 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
         // rounds per iteration on the long instances). B = 64 / 256: 23.4 -> 21.8 / 18.5 -> 17.3 ms; from two workgroups per CU
         // on (B = 512) six or eight wavefronts cost more than they bring
         // (profiles/r04_exp_cfg1_batch_size_and_up_to_8_wavefronts.txt). Same results, bit for bit.
-        if (sizeof(T) == 4 && L.rs < kRegSlotsLarge && !L.glb && 4 * B <= h->n_simd) lw = kSpecWavesWide;
+        // (the 4-slot register table only: what was measured, and what nmpc_hip.h documents -- ADVICE r4)
+        if (sizeof(T) == 4 && L.rs == kRegSlotsSmall && !L.glb && 4 * B <= h->n_simd) lw = kSpecWavesWide;
         // Large batches whose LDS tables allow only a few workgroups per CU (e.g. 40 active obstacle rows: 35 KB,
         // 4 per CU = one wavefront per SIMD): the wavefronts of a latency-kernel workgroup SHARE the instance's
         // tables, so W of them fill the SIMDs that the throughput kernel leaves empty (measured on configs[2]:
@@ -827,7 +841,7 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
         const int wpe_sp = !f32 ? NMPC_WPE_F64 : L.rs >= kRegSlotsLarge ? 2 : NMPC_SPEC_WPE_F32;
         const size_t elem = sizeof(T);
         const int tp = std::min<int>(4 * wpe_tp, (int)(kLdsLimit / ((size_t)L.lds_total * elem)));
-        const int wg_spec = (int)(kLdsLimit / ((size_t)L.lds_total_spec * elem));
+        const int wg_spec = (int)(kLdsLimit / ((size_t)(L.lds_xch + spec_xch_elems(kSpecWaves)) * elem));
         int best = tp;
         for (int w = std::max(lw, 2); w <= kSpecWaves; ++w) {
             const int res = std::min(4 * wpe_sp / w, wg_spec) * w;
@@ -846,7 +860,8 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
     int coop = h->cfg.coop_waves > kSpecWaves ? kSpecWaves : h->cfg.coop_waves;
     if (coop == 0) coop = (L.glb && h->cfg.latency_waves == 0) ? kSpecWaves : 1;
     if (L.rs > 0 || h->cfg.max_solver_time_us > 0 || !h->coop_ok[sizeof(T) == 4 ? 0 : 1]) coop = 1;
-    pl.lds_bytes = (size_t)(waves ? L.lds_total_spec : L.lds_total) * sizeof(T);
+    // (latency kernel: the exchange area by the W actually launched -- about half of the 8-wavefront maximum at W = 4)
+    pl.lds_bytes = (size_t)(waves ? L.lds_xch + spec_xch_elems(waves) : L.lds_total) * sizeof(T);
     pl.fn = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs) : pick_solve<T>(h->lps, L.glb, L.rs);
     pl.has_axis = L.rs > 0 && h->lps == 3 && !L.glb;
     if (pl.has_axis) pl.fn2 = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs, 2) : pick_solve<T>(h->lps, L.glb, L.rs, 2);
@@ -1197,8 +1212,11 @@ int solve_trace(nmpc_handle_s* h, const double* p, const double* u0, const doubl
     if ((rc = h->dcost.reserve(sizeof(double)))) return rc;
     if ((rc = h->dstatus.reserve(sizeof(int32_t)))) return rc;
     if ((rc = h->diters.reserve(2 * sizeof(int32_t)))) return rc;
-    if ((rc = h->dinfo.reserve(8 * sizeof(double)))) return rc;
+    if ((rc = h->dinfo.reserve((8 + nmpc::kProfSlots) * sizeof(double)))) return rc; // (a -DNMPC_PROFILE build writes its slots behind the 8)
     if ((rc = dc0.reserve(sizeof(double)))) return rc;
+    // the handle's staging buffers are shared with nmpc_solve_batch_*: a solve enqueued with sync = 0 must have finished
+    // with them (its results copied out) before this call overwrites them
+    HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpyAsync(h->dP.p, p, np * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (u0) HIP_TRY(hipMemcpyAsync(h->du0.p, u0, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (y0) HIP_TRY(hipMemcpyAsync(h->dy.p, y0, n * sizeof(double), hipMemcpyHostToDevice, h->stream));

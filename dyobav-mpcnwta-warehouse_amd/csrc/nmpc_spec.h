@@ -106,6 +106,8 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     T osv = 0, osw = 0, ogv = 0, ogw = 0, lb_gamma = 1;
     int lb_active = 0, lb_head = 0;
     int lb_first = 1; // (the wave-uniform flags are ints: a bool would live in an SGPR PAIR as a lane mask)
+    constexpr bool kCompactLb = (NMPC_LBFGS_COMPACT & 2) != 0; // the direction in compact form (nmpc_device.h, lbfgs_apply_compact)
+    int lb_new = 0;
     T dyn = 0, dyn_plus = 0, f2n = 0, f2n_plus = 0;
     int alm_iter = 0, inner_total = 0, outer = 1, status = 0;
     int num_iter = 0, lip_it = 0, nls = 0;
@@ -148,6 +150,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     };
     auto reset_cache = [&]() {
         lb_active = 0;
+        lb_new = 0;
         lb_first = true;
         rhs_ls = 0;
         tau = 1;
@@ -389,6 +392,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             if (anyb(cost_half > rhs && L < MAX_L) && lip_it < MAX_LIP) {
                 // gamma is halved: the speculative candidates (if any) are void, continue sequentially
                 lb_active = 0;
+                lb_new = 0;
                 lb_first = true;
                 L *= T(2);
                 gamma *= T(0.5);
@@ -458,7 +462,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             } else {
                 const bool stall = alm_iter == 0 || anyb((dyn_plus <= kc->suff_dec * dyn + SMALL) &&
                                                          (n2 == 0 || f2n_plus <= kc->suff_dec * f2n + SMALL));
-                if (!stall) {
+                if (!stall && !single) { // (single_inner: penalty and multipliers are returned as they came, whatever the outcome)
                     c *= kc->pen_update;
                     inv_cdiv = T(1) / (c > T(1) ? c : T(1));
                 }
@@ -466,8 +470,10 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 alm_iter++;
                 dyn = dyn_plus;
                 f2n = f2n_plus;
-                yv = ypv;
-                yw = ypw;
+                if (!single) {
+                    yv = ypv;
+                    yw = ypw;
+                }
                 reset_cache();
                 if (outer >= kc->max_outer) finished = true;
                 else if (!cont_time) {
@@ -646,18 +652,24 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 rho.set(lb_head, T(1) / ys);
                 lb_gamma = ys / I.dot2(nyv, nyw, nyv, nyw);
                 lb_active = lb_active + 1 < mem ? lb_active + 1 : mem;
+                lb_new = 1;
                 // (no barrier: the master alone writes and reads the ring, and a wavefront's LDS accesses stay in order)
             }
         }
         NMPC_STAMP(I, 12); // L-BFGS update
         if (iteration == 0) { // update_no_linesearch (only reached from SP_LIP)
+            // (no pair can have been accepted here: iteration 0 follows a reset of the buffer, whose first update only records the point)
             uv = hv;
             uw = hw;
             request_uniform(uv, uw, c, true);
             phase = SP_NOLS;
             continue;
         }
-        lbfgs_apply(I, hist, rho, N, kk, mem, lb_head, lb_active, lb_gamma, fv, fw, dv, dw);
+        if constexpr (kCompactLb) {
+            lbfgs_apply_compact(I, hist, lds + cold_args<T>()->lds_lbc, rho, N, kk, mem, lb_head, lb_active, lb_new, lb_gamma, fv, fw, dv, dw);
+            lb_new = 0;
+        } else
+            lbfgs_apply(I, hist, rho, N, kk, mem, lb_head, lb_active, lb_gamma, fv, fw, dv, dw);
         NMPC_STAMP(I, 13); // two-loop recursion
         if (!fbe_valid) {
             const T t1 = sv - hv, t2 = sw - hw;

@@ -78,7 +78,8 @@ def check_protocol_row(row, workload, passing, n):
         assert t["same_status_frac"] >= tf["same_status_frac"] - 0.1 and t["same_status_frac"] >= 0.75, (t, tf)
         assert k["n_unexplained"] == 0 and kf["n_unexplained"] == 0, (k["far_pairs"], kf["far_pairs"])
         # the two evaluators agree at every end point (differences relative to |psi|: the gradient there is ~1e-5)
-        assert k["max_grad_rel_diff_hip_vs_oracle"] < 1e-9 and k["max_psi_rel_diff_hip_vs_oracle"] < 1e-11, k
+        # (at penalties of 1e9 the gradient is a sum of terms ~ c x 1e-9 that cancel: 1e-16 x c in absolute terms)
+        assert k["max_grad_rel_diff_hip_vs_oracle"] < 1e-7 and k["max_psi_rel_diff_hip_vs_oracle"] < 1e-10, k
         if workload != "cfg4":
             assert k["n_both_kkt"] >= 8 and k["max_abs_du_both_kkt"] < 1e-5, k     # (oracle vs twin: 2e-7)
             assert all(min(r["a"]["penalty"], r["b"]["penalty"]) >= 1e5 for r in k["far_pairs"] if r["kind"] == "not_kkt"), k["far_pairs"]

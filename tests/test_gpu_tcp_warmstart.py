@@ -80,8 +80,8 @@ def test_warm_started_closed_loop_is_cheaper_and_as_good():
     assert sum(warm.solve_ms) < 1.25 * sum(cold.solve_ms)     # not a speed-up in general: more robots stay in the run
 
 
-def test_golden_wire_bytes_against_the_oracle():
-    """the request bytes of opengen's client (tests/golden/tcp_wire.json -- recalled, each with its
+def test_recalled_wire_bytes_against_the_oracle():
+    """the request bytes of opengen's client (tests/recalled/tcp_wire.json -- recalled, each with its
     opengen source named) over a RAW socket to the real solver, and the answer document checked against the ORACLE (not
     against the in-process call): controls, exit status, iteration counts, cost, and the multipliers / penalty round trip."""
     import json

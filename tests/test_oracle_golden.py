@@ -112,9 +112,8 @@ def test_fixture_recipe_regenerates_every_fixture_byte_for_byte(tmp_path):
     out = tmp_path / "regen"
     subprocess.run([sys.executable, os.path.join(GOLDEN, "make_golden.py"), str(out)], check=True, capture_output=True,
                    timeout=900)
-    # (tcp_wire.json is not a recording: opengen is absent, its documents are RECALLED and say so -- everything else is
-    #  regenerated from the reference's code)
-    names = sorted(f for f in os.listdir(GOLDEN) if f.endswith((".json", ".npz")) and f != "tcp_wire.json")
+    # (everything under tests/golden/ is a recording of the reference; what is merely RECALLED lives in tests/recalled/)
+    names = sorted(f for f in os.listdir(GOLDEN) if f.endswith((".json", ".npz")))
     assert names == sorted(os.listdir(out))
     for f in names:
         assert filecmp.cmp(os.path.join(GOLDEN, f), os.path.join(out, f), shallow=False), f

@@ -235,9 +235,9 @@ def test_the_references_own_tcp_consumer_accepts_our_answers():
                 sys.modules[k] = v
 
 
-# ---- the recalled wire documents as golden bytes (tests/golden/tcp_wire.json) ----------------------------------------
+# ---- the RECALLED wire documents (tests/recalled/tcp_wire.json: not reference-backed, see tests/recalled/README.md) ----------------------------------------
 def _wire():
-    return json.load(open(os.path.join(ROOT, "tests", "golden", "tcp_wire.json")))
+    return json.load(open(os.path.join(ROOT, "tests", "recalled", "tcp_wire.json")))
 
 
 def _run_bytes(w, p, u0=None, y0=None, c0=None) -> bytes:
@@ -266,7 +266,7 @@ def _raw_bytes(mng, payload: bytes) -> bytes:
     return data
 
 
-def test_golden_wire_bytes_against_the_server(manager):
+def test_recalled_wire_bytes_against_the_server(manager):
     """The exact request bytes opengen's client writes (recalled; each with its opengen source named in the fixture) over a
     raw socket, and the shape of what comes back: field names IN ORDER, JSON types, status strings, error documents."""
     mng, fake = manager

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Measurement of the f3 path (batched closed-loop evaluator): B warehouse scenarios advanced in lock-step; one JSON
 line with scenario-steps/s, the share of the wall time spent inside the solve kernel, and the outcome statistics.
-The comparison figure is the reference's own way of doing this: one scenario after another, one solve per step."""
+The comparison figure is the reference's own way of doing this: one scenario after another, one solve per step.
+   usage: bench_evaluate.py [B] [max_steps] [f32|f64] [n_ped] [n_hyp]
+   n_ped x n_hyp = 2 x 1 (default): the shipped yaml's dimensions with the constant-velocity predictor (Ndynobs = 15);
+   4 x 10: BASELINE configs[2]'s dimensions (Ndynobs = 40), every pedestrian fanned into 10 hypotheses."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,21 +14,16 @@ from dyobav_mpcnwta_warehouse_amd.evaluate import BatchEvaluator
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 max_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 dtype = {"f32": np.float32, "f64": np.float64}[sys.argv[3] if len(sys.argv) > 3 else "f32"]
-rng = np.random.default_rng(13)
-boxes = []
-for i in range(14):
-    c = np.array([1.5 + 1.1 * i, (-1) ** i * rng.uniform(1.6, 2.6)]); hx, hy = rng.uniform(0.3, 0.6, 2)
-    boxes.append([[c[0] + hx, c[1] + hy], [c[0] - hx, c[1] + hy], [c[0] - hx, c[1] - hy], [c[0] + hx, c[1] - hy]])
-starts = np.stack([np.zeros(B), rng.uniform(-0.4, 0.4, B), rng.uniform(-0.3, 0.3, B)], axis=1)
-paths = [[(float(8.0 + rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)))] for _ in range(B)]
-hstart = np.stack([np.stack([rng.uniform(5, 9, B), rng.uniform(2.0, 3.5, B)], 1),
-                   np.stack([rng.uniform(6, 10, B), rng.uniform(-3.5, -2.0, B)], 1)], axis=1)
-hpath = np.stack([np.stack([hstart[:, 0] + np.array([-3.0, -5.0]), hstart[:, 0] + np.array([-6.0, -5.5])], 1),
-                  np.stack([hstart[:, 1] + np.array([-2.5, 5.0]), hstart[:, 1] + np.array([-5.0, 5.5])], 1)], axis=1)
+n_ped = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+n_hyp = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+sc = nm.scenarios.make_closed_loop_scenarios(B, seed=13, n_ped=n_ped)
 cfg = nm.default_config_struct()
-cfg.max_active_dynobs = 2
-BatchEvaluator(cfg, starts[:64], paths[:64], hstart[:64], hpath[:64], np.array(boxes), dtype=dtype).run(max_steps=3)  # warm-up
-ev = BatchEvaluator(cfg, starts, paths, hstart, hpath, np.array(boxes), dtype=dtype, human_stagger=0.2, seed=5)
+if n_ped * n_hyp > cfg.Ndynobs:
+    cfg.Ndynobs = n_ped * n_hyp
+cfg.max_active_dynobs = n_ped * n_hyp
+warm = nm.scenarios.make_closed_loop_scenarios(64, seed=14, n_ped=n_ped)
+BatchEvaluator(cfg, dtype=dtype, n_hyp=n_hyp, **warm).run(max_steps=3)  # warm-up
+ev = BatchEvaluator(cfg, dtype=dtype, human_stagger=0.2, seed=5, n_hyp=n_hyp, **sc)
 if os.environ.get("DISPATCH") == "index":      # (diagnostic: switch the history-based dispatch order off)
     ev.dispatch_by_history = False
 torch.cuda.synchronize()
@@ -37,7 +35,8 @@ scen_steps = int(res.steps.sum())
 print(json.dumps({
     "metric": "scenario time-steps/sec (f3, batched closed-loop evaluation)", "value": scen_steps / el, "unit": "steps/s",
     "n_gpus": 1, "dtype": "f32" if dtype == np.float32 else "f64", "wall_s": el,
-    "config": {"workload": f"B={B} scenarios x <= {max_steps} steps, mpc_fast.yaml, 14 map boxes, 2 pedestrians (CV predictor)"},
+    "config": {"workload": f"B={B} scenarios x <= {max_steps} steps, mpc_fast.yaml, 14 map boxes, {n_ped} pedestrians x {n_hyp} "
+                           f"hypotheses (Ndynobs = {cfg.Ndynobs}; " + ("constant-velocity rows" if n_hyp == 1 else "fan around the constant-velocity prediction") + ")"},
     "lockstep_steps": len(res.solve_ms), "scenario_steps": scen_steps,
     "solve_kernel_ms_total": float(np.sum(res.solve_ms)), "solve_kernel_share": float(np.sum(res.solve_ms)) * 1e-3 / el,
     "solve_kernel_ms_per_step": [round(float(x), 2) for x in res.solve_ms[:6]] + ["..."] + [round(float(x), 2) for x in res.solve_ms[-3:]],
