@@ -175,7 +175,7 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false,
     L.lds_fl = L.lds_fl0 + round4(c.Nother);          // int list: robots with a non-zero t=0 position
     L.lds_iflag = L.lds_fl + round4(c.Nother);         // int list: robots with a non-zero predicted position
     L.lds_hist = L.lds_iflag + round4(c.Ndynobs);  // int flags / compaction map (an int fits in a T)
-    L.lds_rho = L.lds_hist + 4 * nmpc::kMem * N;    // L-BFGS ring: kMem x N x (s_v, s_w, y_v, y_w)
+    L.lds_rho = L.lds_hist + 4 * nmpc::kMem * nmpc::lbfgs_slot_stride(N); // L-BFGS ring: kMem slots x (N | 1) x (s_v, s_w, y_v, y_w)
     L.lds_lbc = L.lds_rho + round4(2 * nmpc::kMem);    // rho[kMem], alpha[kMem]; then the compact-form workspace (16-B aligned)
     L.lds_park = L.lds_lbc + round4(nmpc::lbfgs_compact_elems<float>(N)); // then the parking area(s)
     const int park_one = nmpc::kParkQuads * 4 * 64;    // elements per wavefront

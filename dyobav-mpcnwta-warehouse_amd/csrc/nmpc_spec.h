@@ -647,7 +647,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 if (lead) {
                     int ko = I.k; // (opaque, as above)
                     asm volatile("" : "+v"(ko));
-                    hist[lb_head * N + ko] = Quad<T>{nsv, nsw, nyv, nyw};
+                    hist[lb_head * lbfgs_slot_stride(N) + ko] = Quad<T>{nsv, nsw, nyv, nyw};
                 }
                 rho.set(lb_head, T(1) / ys);
                 lb_gamma = ys / I.dot2(nyv, nyw, nyv, nyw);

@@ -4,7 +4,7 @@ instance of the cfg1 batch alone on the chip.  usage: prof_spec.py [W]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["NMPC_HIP_LIBRARY"] = os.path.join(ROOT, "build", "libnmpc_prof.so")
+os.environ["NMPC_HIP_LIBRARY"] = os.environ.get("PROF_LIB") or os.path.join(ROOT, "build", "libnmpc_prof.so")
 import numpy as np
 import dyobav_mpcnwta_warehouse_amd as nm
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 3
@@ -18,7 +18,7 @@ ms = h.last_kernel_ms()
 prof = info[0, 8:].astype(np.float64); n_it = int(it[0, 1])
 names = {0: "solver -> eval entry", 1: "rollout", 2: "polygons+fleet", 3: "segments", 4: "ellipses", 5: "pad+control+cost", 6: "adjoint",
          7: "eval epilogue", 8: "exchange (LDS + barrier)", 9: "Lipschitz test", 10: "phase code (candidate replay)", 11: "step head",
-         12: "L-BFGS update", 13: "two-loop recursion"}
+         12: "L-BFGS update", 13: "L-BFGS direction (two-loop recursion / compact form)"}
 print(f"W={W}: {ms:.2f} ms, {n_it} inner iterations, {ms*1e-3*2.4e9/n_it:.0f} cycles/iter (wavefront 0's stamps below, ticks per iteration)")
 tot = prof[:14].sum()
 for i in range(14):

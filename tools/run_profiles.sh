@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round profile pass on the GPU box: bench lines + rocprofv3 kernel stats + PMC passes, written to gpurun_out/$1/.
-# Usage (from the repo root, inside gpurun): bash tools/run_profiles.sh r04
+# Usage (from the repo root, inside gpurun): bash tools/run_profiles.sh r05
 set -u
-R=$(pwd); RN=${1:-r04}; OUT=$R/gpurun_out/$RN; mkdir -p $OUT
+R=$(pwd); RN=${1:-r05}; OUT=$R/gpurun_out/$RN; mkdir -p $OUT
 RNUM=$(echo $RN | sed 's/^r0*//')
 export TMPDIR=/tmp
 cd /tmp
@@ -34,14 +34,37 @@ for wl in cfg4:8192:40968:40 cfg1:1024:2778:20; do
   done
   python3 $R/tools/make_traffic_json.py $RNUM $name f32 $batch $np $n $OUT/pmc_${name}_FETCH_SIZE $OUT/pmc_${name}_WRITE_SIZE $OUT/${name}_traffic.json 1 > /dev/null 2>> $OUT/pmc_sq.err
 done
+# 4b. the fp64 N = 40 kernel (configs[4] "fp64 vs fp32 tolerance sweep"): general / compressed streamed table, reduced batch
+(cd $R && bash tools/pmc_cfg4_f64.sh $RN/pmc_cfg4_f64 2048) > $OUT/cfg4_f64_pmc.txt 2>&1
+python3 - <<PY > $OUT/cfg4_f64_traffic.json 2>> $OUT/pmc_sq.err
+import json, re
+out = {"round": $RNUM, "workload": "cfg4", "dtype": "f64", "batch": 2048, "family": "toward_robot",
+       "command": "tools/pmc_cfg4_f64.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_* (separate passes) -- python3 bench.py --workload cfg4 --dtype f64 --batch 2048 --steps 1 --warmup 0 [--axis-aligned -1]",
+       "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; unit KB"}
+for tag in ("general", "compressed"):
+    t = open("$OUT/pmc_cfg4_f64/pmc_summary_%s.txt" % tag).read()
+    g = lambda k: float(re.search(k + r"\s+([0-9.e+]+)", t).group(1))
+    b = json.loads(open("$OUT/pmc_cfg4_f64/bench_%s.json" % tag).read().strip().splitlines()[-1])
+    hbm = (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024
+    ms = b["roofline"]["kernel_ms"]
+    out[tag] = {"kernel": b["roofline"]["kernel"], "solves_per_s": b["value"], "kernel_ms": ms, "psi_evals_per_solve": b["roofline"]["psi_evals_per_solve"],
+                "FETCH_SIZE_KB": g("FETCH_SIZE"), "WRITE_SIZE_KB": g("WRITE_SIZE"), "hbm_bytes_per_launch": hbm,
+                "hbm_TB_per_s": hbm / (ms * 1e-3) / 1e12, "frac_of_8TBps_peak": hbm / (ms * 1e-3) / 8e12,
+                "SQ_INSTS_VALU": g("SQ_INSTS_VALU"), "SQ_WAIT_ANY_over_WAVE_CYCLES": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")}
+print(json.dumps(out, indent=1))
+PY
 # 5. the next-row components
 python3 $R/tools/bench_assemble.py 2>/dev/null | tail -1 > $OUT/f1_assemble_bench.json
 python3 $R/tools/bench_hypotheses.py 2>/dev/null | tail -1 > $OUT/f2_hypotheses_bench.json
 python3 $R/tools/bench_evaluate.py 4096 60 f32 2>/dev/null | tail -1 > $OUT/f3_evaluate_b4096.json
 python3 $R/tools/bench_evaluate.py 1 60 f64 2>/dev/null | tail -1 > $OUT/f3_evaluate_b1_f64.json
 python3 $R/tools/bench_evaluate.py 65536 60 f32 2>/dev/null | tail -1 > $OUT/f3_evaluate_b65536.json
+# ... and at BASELINE configs[2]'s dimensions: 4 pedestrians x 10 hypotheses (Ndynobs = 40), the closed loop itself
+python3 $R/tools/bench_evaluate.py 65536 60 f32 4 10 2>/dev/null | tail -1 > $OUT/f3_evaluate_b65536_4x10.json
 python3 $R/tools/solo_latency.py 2>/dev/null | grep "instance" > $OUT/solo_latency.txt
 python3 $R/tools/kernel_resources.py > $OUT/kernel_resources.txt 2>/dev/null
-python3 $R/tools/exp_cfg1_waves.py > $OUT/exp_cfg1_waves.txt 2>/dev/null
-python3 $R/tools/exp_polish_stats.py cfg2 1024 > $OUT/polish_stats_cfg2.txt 2>/dev/null
+python3 $R/tools/exp_three_per_wave.py > $OUT/exp_three_instances_per_wavefront.txt 2>/dev/null
+# 6. the closed-loop family of configs[2] under the kernel trace (same kernels as the headline, another distribution)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cl -- $B $LEAN --family closed_loop --steps 3 > $OUT/cfg2_closed_loop_bench_under_rocprof.json 2> $OUT/stats_cl.err
+find $OUT/stats_cl -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/cfg2_closed_loop_kernel_stats.csv
 ls $OUT
