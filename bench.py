@@ -239,7 +239,10 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
         glb = False
     # (cooperative kernels on the global table are pairs too: <.., true, 1> streams the compressed table of axis-aligned ellipses)
     ctail = f",true,{member}" if (glb and member and waves == -4) else ""
+    if dtype == "f64" and not tail and lps == 3 and waves == 0 and member and launch["axis_aligned"] >= 0:
+        tail = f",false,14,{member}"                 # (the fp64 register-table kernel: one wavefront per SIMD, 14 slots)
     kernel_name = (f"solve_spec_kernel<{tname},{lps}{tail}> W={waves}" if waves > 0
+                   else f"solve_coop_reg_kernel<{'true' if 33 <= layout.N <= 42 else 'false'}> W=8" if waves == -8
                    else f"solve_coop_kernel<{tname},{lps}{ctail}> W={-waves}" if waves < 0
                    else f"solve_kernel<{tname},{lps}{tail}>")
     kernel_desc = ("latency mode: several wavefronts per instance, speculative line search" if waves > 0
@@ -423,7 +426,7 @@ def accuracy_digest(acc) -> dict:
         if row.get("divergence_audit"):
             a = row["divergence_audit"]
             d["audit"] = {"far": a.get("n_far", a["n_pairs"]), "audited": a["n_pairs"], "unexpl": a["n_unexplained"],
-                          "twin_far": a["oracle_vs_reassociated"].get("n_far"), "twin_unexpl": a["oracle_vs_reassociated"]["n_unexplained"]}
+                          "twin_unexpl": a["oracle_vs_reassociated"]["n_unexplained"]}
         for cmp_, short in (("tight_kkt_hip64_vs_oracle64", "tight_hip_orc"), ("tight_kkt_oracle64_vs_reassociated", "tight_orc_twin")):
             k = row.get(cmp_)
             if k and k["n_pairs"]:
@@ -437,7 +440,8 @@ def accuracy_digest(acc) -> dict:
         if st and st["all"].get("n"):
             d["ret_f32pol"] = {"n": st["all"]["n"], "lt1e-4": _r(st["all"]["frac_lt_1e-4"], 3), "lt1e-3": _r(st["all"]["frac_lt_1e-3"], 3),
                                "conv_lt1e-4": _r(st["converged"].get("frac_lt_1e-4"), 3)}
-        if d:
+        # (the line carries the families where a comparison is well posed: a good share converges; bench_detail.json has all)
+        if d and row["family"] != "toward_robot":
             out[f"{row['workload']}_{row['family']}"] = d
     return out
 
@@ -468,7 +472,7 @@ def compact_line(detail: dict) -> str:
         if cl:
             out["closed_loop"] = {"solves_per_s": _r(cl[0]["value"], 4), "converged_frac": _r(cl[0]["converged_frac"], 3),
                                   "psi_evals_per_solve": _r(cl[0]["psi_evals_per_solve"], 4), "kernel_ms": _r(cl[0]["kernel_ms"], 4),
-                                  "capture_steps": cl[0]["harvest"]["capture_steps"]}
+                                  "capture_steps": list(CLOSED_LOOP_STEPS)}
     if "accuracy" in detail:
         out["accuracy_summary"] = accuracy_digest(detail["accuracy"])
     out["detail"] = "bench_detail.json"

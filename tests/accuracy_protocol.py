@@ -281,8 +281,9 @@ def config_for_layout(nm, layout, n_active, **overrides):
 
 def run_case(nm, oracle, workload: str, family: str, n: int | None = None, seed: int = 1234, nthreads: int = 8,
              tight: bool = True, akkt_form: int = 0, audit: bool = False, audit_max: int = 24, tight_audit: bool | None = None,
-             n_tight: int | None = None) -> dict:
-    """One (configuration, family) row of the table: seeded instances of the BASELINE generator."""
+             n_tight: int | None = None, n_polish: int | None = None) -> dict:
+    """One (configuration, family) row of the table: seeded instances of the BASELINE generator. ``n_polish``: the polish
+    legs (device against device, no oracle involved) on their own, larger sample of that many instances."""
     key, n_default = WORKLOADS[workload]
     spec = dict(nm.scenarios.BENCH_CONFIGS[key])
     layout = spec.pop("layout")
@@ -290,14 +291,15 @@ def run_case(nm, oracle, workload: str, family: str, n: int | None = None, seed:
     spec.pop("seed")
     n = n or n_default
     P = nm.scenarios.make_batch(n, layout, seed=seed, ped_mode=family, **spec)
+    P_polish = None if not n_polish else nm.scenarios.make_batch(n_polish, layout, seed=seed + 1, ped_mode=family, **spec)
     return run_case_on(nm, oracle, P, layout, spec["n_ped"] * spec["n_hyp"], workload, family, nthreads=nthreads, tight=tight,
                        akkt_form=akkt_form, audit=audit, audit_max=audit_max, tight_audit=tight_audit,
-                       fixed_point=workload != "cfg4", n_tight=n_tight)
+                       fixed_point=workload != "cfg4", n_tight=n_tight, P_polish=P_polish)
 
 
 def run_case_on(nm, oracle, P, layout, n_active: int, workload: str, family: str, nthreads: int = 8, tight: bool = True,
                 akkt_form: int = 0, audit: bool = False, audit_max: int = 24, tight_audit: bool | None = None,
-                fixed_point: bool = True, polish: bool = True, n_tight: int | None = None) -> dict:
+                fixed_point: bool = True, polish: bool = True, n_tight: int | None = None, P_polish=None) -> dict:
     """The protocol on a given parameter batch ``P[n, np]`` (fp64) of the dimensions ``layout`` with at most ``n_active``
     non-zero obstacle rows -- the BASELINE generators (run_case) or batches harvested from the closed loop
     (scenarios.harvest_closed_loop). ``n_tight``: the tolerance-1e-8 legs (whose CPU side runs up to 2000 x 15
@@ -340,9 +342,13 @@ def run_case_on(nm, oracle, P, layout, n_active: int, workload: str, family: str
     # fp64 continuation of the converged instances (the continuation runs with OpEn's own fp64 Lipschitz step)
     open_step = dict(lip_eps_f64=1e-6, lip_delta_f64=1e-12)
     if polish:
+        if P_polish is not None:     # (device against device: a larger sample of its own costs no oracle time)
+            P_keep, P = P, np.ascontiguousarray(P_polish, dtype=np.float64)
         r32p, r64p = hip(np.float32, polish=1, **open_step), hip(np.float64, polish=1, **open_step)
+        if P_polish is not None:
+            P = P_keep
         p32, p64 = r32p["info"][:, 6] == 1, r64p["info"][:, 6] == 1
-        row["polish"] = {"selected32": int((r32p["info"][:, 6] >= 1).sum()), "replaced32": int(p32.sum()),
+        row["polish"] = {"n": int(len(p32)), "selected32": int((r32p["info"][:, 6] >= 1).sum()), "replaced32": int(p32.sum()),
                          "selected64": int((r64p["info"][:, 6] >= 1).sum()), "replaced64": int(p64.sum())}
         row["hip32polish_vs_hip64polish"] = _stats_mask(r32p["U"], r64p["U"], p32 & p64)
     if tight:
@@ -388,7 +394,7 @@ def run_case_on(nm, oracle, P, layout, n_active: int, workload: str, family: str
             row["divergence_audit_tight"]["n_far"] = int(len(fa))
             row["divergence_audit_tight"]["oracle_vs_reassociated"]["n_far"] = int(len(fr))
         # the fixed point itself: fp64 from scratch at 1e-8 with OpEn's own Lipschitz step
-        if not fixed_point or not polish:  # (N = 40 in fp64 from scratch at 1e-8: minutes; the polish rows above stand alone)
+        if not fixed_point or not polish or P_polish is not None:  # (N = 40 in fp64 from scratch at 1e-8: minutes; the polish rows above stand alone)
             return row
         r64f = hip(np.float64, **caps, **TIGHT, **open_step)
         t_ok = r64f["status"] == 0

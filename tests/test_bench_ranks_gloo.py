@@ -92,6 +92,20 @@ def test_bench_line_is_compact_with_every_optional_part():
     assert len(rec["secondary_solves_per_s"]) == len(detail["secondary"])          # no two rows share a name
     assert all(isinstance(v, (int, float)) for v in rec["secondary_solves_per_s"].values())
     assert abs(rec["value"] - detail["value"]) < 1e-4 * detail["value"]
+    # ... and on round 5's record (nested accuracy digest, closed-loop rows, the tight-tolerance KKT keys)
+    d5 = json.load(open(os.path.join(ROOT, "profiles", "r05_cfg2_bench_detail_first.json")))
+    line5 = bench.compact_line(d5)
+    assert "\n" not in line5 and len(line5) < bench.LINE_TARGET_BYTES, len(line5)
+    rec5 = json.loads(line5)
+    assert rec5["config"]["max_active_dynobs"] == 40                      # the capacity hint is stated in the line
+    assert {"cfg2_closed_loop_f32", "cfg1_f32_nohint", "cfg4_f64"} <= set(rec5["secondary_solves_per_s"])
+    assert rec5["closed_loop"]["solves_per_s"] == rec5["secondary_solves_per_s"]["cfg2_closed_loop_f32"]
+    assert 0 < rec5["closed_loop"]["converged_frac"] < 1 and rec5["closed_loop"]["psi_evals_per_solve"] > 0
+    acc = rec5["accuracy_summary"]
+    assert {"cfg2_passing", "cfg2_closed_loop", "cfg1_passing"} <= set(acc)
+    for k in ("cfg2_passing", "cfg2_closed_loop", "cfg1_passing"):
+        assert acc[k]["tight_hip_orc"]["unexpl"] == 0 and acc[k]["tight_orc_twin"]["unexpl"] == 0 and acc[k]["audit"]["unexpl"] == 0
+        assert acc[k]["tight_hip_orc"]["kkt_max_du"] < 1e-4            # both end points stationary -> inside the north star's bar
     detail["config"]["padding"] = "x" * 9000
     detail2 = dict(detail, config=dict(detail["config"], workload="y" * 9000))
     with pytest.raises(RuntimeError):

@@ -277,7 +277,8 @@ def test_loop_kernels_refuse_host_pointers():
         a.max_steps, a.step, a.M = 4, 0, 0
         for name, _ in _capi.NmpcLoopArgs._fields_:
             if name not in ("B", "n_run", "H", "W", "Lmax", "M", "step", "max_steps", "run", "base_speed", "lin_vel_max",
-                            "human_size", "human_vmax", "gather_y", "reserved", "polys", "stagger"):
+                            "human_size", "human_vmax", "gather_y", "n_hyp", "hyp_fan_rad", "hyp_radius0", "hyp_radius_growth", "polys",
+                            "stagger"):
                 setattr(a, name, host.ctypes.data)
         with pytest.raises(nm.NmpcError, match="device pointer"):
             h.loop_step(np.float64, a, post=False)
