@@ -462,7 +462,7 @@ def compact_line(detail: dict) -> str:
     if "cpu_baseline" in detail:
         cb = detail["cpu_baseline"]
         out["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind", "sample", "single_core_value", "value_trig_hoisted",
-                                                      "value_with_reference_time_cap", "converged_frac", "open_probe")
+                                                      "value_with_reference_time_cap", "converged_frac", "closed_loop_value", "open_probe")
                                if k in cb}
     if "secondary" in detail:
         out["secondary_solves_per_s"] = {secondary_key(r): _r(r["value"], 4) for r in detail["secondary"]}
@@ -617,7 +617,26 @@ def cpu_baseline(layout, P_host):
     t0 = time.perf_counter()
     _, rc = oracle.solve_batch(pr, oracle.Options(max_time_s=cap_s), Ps, nthreads=cores)
     t_cap = time.perf_counter() - t0
-    return {"value": sample / t_all, "unit": "solves/s", "cores": cores, "kind": "port",
+    # ... and on the closed-loop distribution of the same dimensions (configs[2] only: BASELINE's "main_eva.py scenarios",
+    # scenarios.harvest_closed_loop -- the GPU row next to it is secondary_solves_per_s.cfg2_closed_loop_f32)
+    closed = None
+    if layout.N == 20 and layout.Ndyn == 40:
+        try:
+            import dyobav_mpcnwta_warehouse_amd as nm
+            cfg = nm.default_config_struct()
+            cfg.Ndynobs, cfg.max_active_dynobs = layout.Ndyn, 40
+            Pc, _ = nm.scenarios.harvest_closed_loop(cfg, max(3 * sample // 2, 96), steps=CLOSED_LOOP_STEPS, seed=13, n_ped=4, n_hyp=10,
+                                                     dtype=np.float32)
+            Pc = np.ascontiguousarray(Pc[:sample], dtype=np.float64)
+            t0 = time.perf_counter()
+            _, rcl = oracle.solve_batch(pr, oracle.Options(), Pc, nthreads=cores)
+            t_cl = time.perf_counter() - t0
+            closed = {"value": len(Pc) / t_cl, "sample": f"{len(Pc)} harvested instances, fp64, {t_cl:.1f} s wall",
+                      "converged_frac": float(np.mean(rcl["status"] == 0))}
+        except Exception as exc:      # (the harvest needs the device; the baseline of the timed batch above must survive without)
+            closed = {"error": repr(exc)[:200]}
+    return {"value": sample / t_all, "unit": "solves/s", "cores": cores, "kind": "port", "closed_loop": closed,
+            "closed_loop_value": None if not closed else closed.get("value"),
             "note": "fp64 restatement run to its iteration caps: the reference's own solver would be cut off at its "
                     "max_solver_time (0.1 s per solve, mpc_builder.py:189) -- at %.0f ms per solve on one core most of "
                     "these solves would end NotConvergedOutOfTime there. Reported, not a target." % (1e3 * t_one / n1),

@@ -93,7 +93,7 @@ def test_bench_line_is_compact_with_every_optional_part():
     assert all(isinstance(v, (int, float)) for v in rec["secondary_solves_per_s"].values())
     assert abs(rec["value"] - detail["value"]) < 1e-4 * detail["value"]
     # ... and on round 5's record (nested accuracy digest, closed-loop rows, the tight-tolerance KKT keys)
-    d5 = json.load(open(os.path.join(ROOT, "profiles", "r05_cfg2_bench_detail_first.json")))
+    d5 = json.load(open(os.path.join(ROOT, "profiles", "r05_cfg2_bench_detail.json")))
     line5 = bench.compact_line(d5)
     assert "\n" not in line5 and len(line5) < bench.LINE_TARGET_BYTES, len(line5)
     rec5 = json.loads(line5)
