@@ -104,7 +104,7 @@ constexpr size_t kLdsLimit = 160 * 1024; // bytes of LDS one workgroup may use o
 
 int round4(int x) { return (x + 3) & ~3; }
 // exchange area of a latency-kernel workgroup of W wavefronts (nmpc_spec.h: xch + command area)
-int spec_xch_elems(int W) { return round4(W * (2 * 64 + 4) + 2 * 64 * W + 4); }
+int spec_xch_elems(int W) { return round4(W * (2 * 64 + 4) + 2 * 64 * W + 8); } // (+ 8 command scalars: c, 1/max(c,1), flags, exit, gamma, 1/gamma)
 
 constexpr int kRegSlotsSmall = 4, kRegSlotsLarge = 14; // compiled register-table sizes (rows = 3 x slots)
 constexpr int kRegSlotsCoop = 12; // one lane per step: 8 cooperating wavefronts (2 per SIMD, 256 registers each) x 12 slots in

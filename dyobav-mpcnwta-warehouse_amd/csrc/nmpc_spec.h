@@ -208,6 +208,12 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         yv = tclamp(yv, T(-1e12), T(1e12));
         yw = tclamp(yw, T(-1e12), T(1e12));
     }
+    // The solver options the master consults in EVERY iteration, read once (round 5): re-read from the kernel argument at the
+    // point of use -- what the throughput kernels do to keep their scalar registers free -- each of them is a scalar load
+    // whose ~200-cycle round trip the lone master wavefront waits for with nobody to fill it (three per iteration); a
+    // scalar register that ends up spilled to a VGPR lane costs one v_readlane instead.
+    const T o_tol = kp.tol, o_sy_eps = kp.sy_eps, o_cbfgs_eps = kp.cbfgs_eps, o_cbfgs_alpha = kp.cbfgs_alpha;
+    const int o_max_inner = kp.max_inner, o_akkt_form = kp.akkt_form;
     int phase = SP_INIT_A;
     T ev = uv, ew = uw, ec = c;
     T inv_cdiv = T(1) / (c > T(1) ? c : T(1));
@@ -251,6 +257,8 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             cmds[1] = inv_cdiv;
             reinterpret_cast<int*>(cmds + 2)[0] = flags;
             reinterpret_cast<int*>(cmds + 2)[1] = 0;
+            cmds[4] = gamma;     // (the candidates' FBE is formed by whoever evaluates them, below)
+            cmds[5] = inv_gamma;
         }
         __syncthreads(); // (A) the workers start
     };
@@ -283,6 +291,8 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             yw = cmd[64 + I.lane];
             ec = c = cmds[0];
             inv_cdiv = cmds[1];
+            gamma = cmds[4];
+            inv_gamma = cmds[5];
             want_grad = 1;
             exchange = 1;
         }
@@ -298,6 +308,28 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 I.template eval<false, NMPC_SPEC_FLAT != 0>(ev, ew, ec, e_icd, yv, yw, r_psi, r_f2, r_gv, r_gw);
             if (kSpecPark) unpark();
         }
+        // The forward-backward envelope of a line-search candidate -- the left-hand side of its acceptance test -- by the
+        // wavefront that evaluated it (round 5): psi - gamma/2 ||grad||^2 + ||gradient_step - Proj_U(gradient_step)||^2 / (2 gamma)
+        // at the candidate (ev, ew). ONE code site for every role, the master included, so a candidate's value does not
+        // depend on who evaluated it (nor on W). Rounds 2-4 had the master recompute this for every candidate it replayed:
+        // two LDS reads, the projection and two wave reductions per candidate, ~4.5 candidates per iteration on its serial path.
+        T fbe = 0;
+        if (exchange && do_eval && want_grad) {
+            T s1, s2;
+            if constexpr (sizeof(T) == 4) {
+                s1 = __builtin_fmaf(-gamma, r_gv, ev);
+                s2 = __builtin_fmaf(-gamma, r_gw, ew);
+            } else {
+                s1 = __builtin_fma(-gamma, r_gv, ev);
+                s2 = __builtin_fma(-gamma, r_gw, ew);
+            }
+            T h1 = s1, h2 = s2;
+            project(h1, h2);
+            const T t1 = s1 - h1, t2 = s2 - h2;
+            T d2, gg;
+            I.dot2x2(t1, t2, t1, t2, r_gv, r_gw, r_gv, r_gw, d2, gg);
+            fbe = r_psi - T(0.5) * gamma * gg + T(0.5) * d2 * inv_gamma;
+        }
         NMPC_STAMP(I, 7); // (eval epilogue)
         const T* xr = xch; // results of this round, one row per role
         if (exchange) {
@@ -307,7 +339,10 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                     xw[2 * I.lane] = r_gv;
                     xw[2 * I.lane + 1] = r_gw;
                 }
-                if (I.lane == 0) xw[2 * 64] = r_psi;
+                if (I.lane == 0) {
+                    xw[2 * 64] = r_psi;
+                    xw[2 * 64 + 1] = fbe;
+                }
             }
             __syncthreads(); // (B) the round's results are in; the workers go back to (A), which also keeps them from
                              //     overwriting these rows before the master has replayed the round
@@ -324,25 +359,23 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         // sequential line-search logic replayed on the exchanged results of wavefronts first..W-1
         auto process_candidates = [&](int first) -> bool {
             for (int w = first; w < W; ++w) {
-                pv = ls_point(uv, fv, dv, tau);
-                pw = ls_point(uw, fw, dw, tau);
-                cost_value = xr[w * XS + 2 * 64];
-                gv = xr[w * XS + 2 * I.lane];
-                gw = xr[w * XS + 2 * I.lane + 1];
                 alg_psi++;
                 alg_grad++;
-                grad_step_half(pv, pw);
-                const T t1 = sv - hv, t2 = sw - hw;
-                T d2, gg;
-                I.dot2x2(t1, t2, t1, t2, gv, gw, gv, gw, d2, gg);
-                const T lhs = cost_value - T(0.5) * gamma * gg + T(0.5) * d2 * inv_gamma;
-                fbe_cur = lhs;
-                fbe_valid = true;
+                const T lhs = xr[w * XS + 2 * 64 + 1]; // the candidate's FBE, formed by the wavefront that evaluated it
                 if (anyb(lhs > rhs_ls) && nls < MAX_LS) {
                     tau *= T(0.5);
                     nls++;
                     continue;
                 }
+                // accepted: the candidate becomes the iterate -- its point, cost, gradient, gradient step and half step
+                pv = ls_point(uv, fv, dv, tau);
+                pw = ls_point(uw, fw, dw, tau);
+                cost_value = xr[w * XS + 2 * 64];
+                gv = xr[w * XS + 2 * I.lane];
+                gw = xr[w * XS + 2 * I.lane + 1];
+                grad_step_half(pv, pw);
+                fbe_cur = lhs;
+                fbe_valid = true;
                 uv = pv;
                 uw = pw;
                 return true;
@@ -569,7 +602,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 step_head = false;
             } else {
                 num_iter++;
-                cont = num_iter < cold_args<T>()->max_inner;
+                cont = num_iter < o_max_inner;
                 if (timed) cont_time = (long long)t_now <= time_budget;
                 step_head = true;
             }
@@ -587,9 +620,8 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             T ff, aa;
             I.dot2x2(fv, fw, fv, fw, a1, a2, a1, a2, ff, aa);
             norm_fpr = tsqrt(ff);
-            const auto* kc = cold_args<T>();
-            const T akkt = kc->akkt_form ? tsqrt(aa) * inv_gamma : tsqrt(aa); // (nmpc_config.akkt_form)
-            if (anyb(norm_fpr < kc->tol && akkt < akkt_tol)) {
+            const T akkt = o_akkt_form ? tsqrt(aa) * inv_gamma : tsqrt(aa); // (nmpc_config.akkt_form)
+            if (anyb(norm_fpr < o_tol && akkt < akkt_tol)) {
                 inner_exit = true;
             } else {
                 lip_it = 0;
@@ -628,8 +660,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             T ys, ss;
             I.dot2x2(nsv, nsw, nyv, nyw, nsv, nsw, nsv, nsw, ys, ss);
             bool ok = true;
-            const auto* kc = cold_args<T>();
-            const T sy_eps = kc->sy_eps, cbfgs_eps = kc->cbfgs_eps, cbfgs_alpha = kc->cbfgs_alpha;
+            const T sy_eps = o_sy_eps, cbfgs_eps = o_cbfgs_eps, cbfgs_alpha = o_cbfgs_alpha;
             if (ss <= Lim<T>::min_pos || (sy_eps > T(0) && ys <= sy_eps)) {
                 ok = false;
             } else if (cbfgs_eps > T(0) && cbfgs_alpha > T(0)) {

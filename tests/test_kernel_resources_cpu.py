@@ -58,9 +58,12 @@ def test_fp32_latency_and_cooperative_kernels_spill_little(resources):
         # (round 4: the solver's integer state stays in scalar registers all the way round the loop -- no v_readfirstlane per
         #  variable and evaluation any more -- and the master / worker split added the command addresses: ~30 SGPRs take
         #  the v_writelane / v_readlane route, outside the evaluation; measured +6.5 % and +5.8 % on configs[1] all the same)
-        assert r["sgpr_spill"] <= 36, (name, r)
-        # (general path of the register-table variants: ~16 VGPRs in scratch; the axis-aligned 4-slot member: 2)
-        assert r["scratch"] <= (72 if general else 16 if axis else 0), (name, r)
+        # (round 5: the options the master consults in every iteration are read once instead of per phase -- six more scalar
+        #  values alive round the loop, up to 47 spilled: a v_readlane where the lone master wavefront waited ~200 cycles for a
+        #  scalar load; with the candidates' FBE formed by the wavefront that evaluated them +1.8 % on configs[1])
+        assert r["sgpr_spill"] <= 48, (name, r)
+        # (general path of the register-table variants: up to 23 VGPRs in scratch; the axis-aligned members: 0 / 9 dwords)
+        assert r["scratch"] <= (96 if general else 40 if axis else 0), (name, r)
     sel = _sel(resources, r"solve_coop(_reg)?_kernel<(float|true|false)")
     assert any("coop_reg" in n for n in sel)          # (the on-chip kernels are named <true> / <false>: they must not drop out)
     for name, r in sel.items():

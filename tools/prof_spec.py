@@ -8,7 +8,7 @@ os.environ["NMPC_HIP_LIBRARY"] = os.environ.get("PROF_LIB") or os.path.join(ROOT
 import numpy as np
 import dyobav_mpcnwta_warehouse_amd as nm
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-P = nm.scenarios.make_batch(1024, seed=0).astype(np.float32)[171:172]
+P = nm.scenarios.make_batch(1024, seed=0).astype(np.float32)[709:710]
 cfg = nm.default_config_struct(); cfg.max_active_dynobs = 10; cfg.latency_waves = W
 h = nm.Handle(cfg)
 U = np.empty((1, 40), np.float32); info = np.empty((1, 24), np.float32); it = np.empty((1, 2), np.int32)
