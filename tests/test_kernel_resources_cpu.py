@@ -59,9 +59,9 @@ def test_fp32_latency_and_cooperative_kernels_spill_little(resources):
         #  variable and evaluation any more -- and the master / worker split added the command addresses: ~30 SGPRs take
         #  the v_writelane / v_readlane route, outside the evaluation; measured +6.5 % and +5.8 % on configs[1] all the same)
         # (round 5: the options the master consults in every iteration are read once instead of per phase -- six more scalar
-        #  values alive round the loop, up to 47 spilled: a v_readlane where the lone master wavefront waited ~200 cycles for a
+        #  values alive round the loop, up to 50 spilled: a v_readlane where the lone master wavefront waited ~200 cycles for a
         #  scalar load; with the candidates' FBE formed by the wavefront that evaluated them +1.8 % on configs[1])
-        assert r["sgpr_spill"] <= 48, (name, r)
+        assert r["sgpr_spill"] <= 52, (name, r)
         # (general path of the register-table variants: up to 23 VGPRs in scratch; the axis-aligned members: 0 / 9 dwords)
         assert r["scratch"] <= (96 if general else 40 if axis else 0), (name, r)
     sel = _sel(resources, r"solve_coop(_reg)?_kernel<(float|true|false)")
