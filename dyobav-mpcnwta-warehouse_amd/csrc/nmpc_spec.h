@@ -719,6 +719,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             want_grad = false;
             do_eval = true;
             request_candidates(1);
+            NMPC_STAMP(I, 14); // (diagnostic: forming the requests + barrier A)
             phase = SP_SPEC0;
         } else {
             request_candidates(0);
