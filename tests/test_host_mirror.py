@@ -118,3 +118,29 @@ def test_solver_build_writes_importable_module(tmp_path):
     finally:
         sys.path.pop(0)
         sys.modules.pop("navi_fast", None)
+
+
+def test_closed_loop_scenarios_are_deterministic_and_well_formed():
+    """scenarios.make_closed_loop_scenarios (the inputs of the batched closed-loop evaluator, row f3, and of
+    harvest_closed_loop): deterministic in (B, seed, n_ped); shapes; pedestrians start on either side of the aisle and
+    cross it; the robot's goal lies ~8 m ahead. (No GPU: the generator is host-side numpy.)"""
+    import numpy as np
+    from dyobav_mpcnwta_warehouse_amd import scenarios
+    a = scenarios.make_closed_loop_scenarios(50, seed=13, n_ped=4)
+    b = scenarios.make_closed_loop_scenarios(50, seed=13, n_ped=4)
+    c = scenarios.make_closed_loop_scenarios(50, seed=14, n_ped=4)
+    for k in ("robot_starts", "human_starts", "human_paths", "map_polygons"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["robot_paths"] == b["robot_paths"] and not np.array_equal(a["human_starts"], c["human_starts"])
+    assert a["robot_starts"].shape == (50, 3) and a["human_starts"].shape == (50, 4, 2)
+    assert a["human_paths"].shape == (50, 4, 2, 2) and a["map_polygons"].shape == (14, 4, 2)
+    assert len(a["robot_paths"]) == 50 and all(len(p) == 1 and 7.4 <= p[0][0] <= 8.6 for p in a["robot_paths"])
+    hs, hp = a["human_starts"], a["human_paths"]
+    assert np.all(np.abs(hs[..., 1]) >= 2.0) and np.all(np.sign(hp[:, :, 0, 1]) == -np.sign(hs[..., 1]))   # they cross the aisle
+    assert np.all(hp[:, :, 0, 0] < hs[..., 0])                                                              # ... towards the robot
+    # the shelf blocks line the aisle on both sides and leave it free
+    cy = a["map_polygons"][:, :, 1].mean(axis=1)
+    assert (cy > 0).sum() == 7 and (cy < 0).sum() == 7 and np.all(np.abs(a["map_polygons"][:, :, 1]).min(axis=1) >= 1.0)
+    with __import__("pytest").raises(AssertionError):
+        from dyobav_mpcnwta_warehouse_amd.scenarios import ParamLayout, make_batch
+        make_batch(2, ParamLayout(20, 10, 10, 15), n_ped=4, n_hyp=10)       # 40 rows do not fit Ndynobs = 15

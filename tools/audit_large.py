@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""The noise-floor / first-divergence protocol of tests/accuracy_protocol.py on larger samples than the test-suite runs
-(TEST INFRASTRUCTURE: imports the oracle).   usage: audit_large.py [n]"""
+"""The noise-floor / first-divergence / tight-tolerance KKT protocol of tests/accuracy_protocol.py on larger samples than
+the test-suite runs (TEST INFRASTRUCTURE: imports the oracle).
+   usage: audit_large.py [n] [n_tight] [families: passing closed_loop ...]
+   `passing`: configs[1] and configs[2] generators; `closed_loop`: parameter vectors harvested from the closed loop at
+   configs[2]'s dimensions (scenarios.harvest_closed_loop). Every far pair is audited (no truncation)."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,14 +12,37 @@ import dyobav_mpcnwta_warehouse_amd as nm
 import oracle
 import accuracy_protocol as ap
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-for wl in ("cfg1", "cfg2"):
-    row = ap.run_case(nm, oracle, wl, "passing", n=n, nthreads=16, tight=False, audit=True, audit_max=10 ** 6)
+n_tight = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+families = sys.argv[3:] or ["passing"]
+
+
+def digest(row, wl, fam):
     au = row["divergence_audit"]
-    out = {"workload": wl, "family": "passing", "n": n,
+    out = {"workload": wl, "family": fam, "n": row["n"], "converged_frac": row["converged_frac"],
            "hip64_vs_oracle64": row["hip64_vs_oracle64"], "hip64tp_vs_oracle64": row["hip64tp_vs_oracle64"],
            "oracle64_vs_reassociated": row["oracle64_vs_reassociated"],
            "audit_hip_vs_oracle": {k: v for k, v in au.items() if k not in ("pairs", "oracle_vs_reassociated")},
            "audit_oracle_vs_reassociated": {k: v for k, v in au["oracle_vs_reassociated"].items() if k != "pairs"},
            "kinds_hip": {k: sum(p.get("kind") == k for p in au["pairs"]) for k in sorted({p.get("kind") for p in au["pairs"]})},
            "unexplained_pairs": [p for p in au["pairs"] if not p["explained"]] + [p for p in au["oracle_vs_reassociated"]["pairs"] if not p["explained"]]}
-    print(json.dumps(out), flush=True)
+    if "tight_kkt_hip64_vs_oracle64" in row:
+        out["n_tight"] = row["n_tight"]
+        for k in ("hip64_vs_oracle64_tight", "oracle64_vs_reassociated_tight", "tight_kkt_hip64_vs_oracle64", "tight_kkt_oracle64_vs_reassociated"):
+            out[k] = row[k]
+    return out
+
+
+for fam in families:
+    if fam == "closed_loop":
+        lay = nm.scenarios.BENCH_CONFIGS["cfg2_b65536_n20_4x10"]["layout"]
+        cfg = nm.default_config_struct()
+        cfg.Ndynobs, cfg.max_active_dynobs = lay.Ndyn, 40
+        P, _ = nm.scenarios.harvest_closed_loop(cfg, max(3 * n // 2, 96), steps=(1, 8, 20), seed=13, n_ped=4, n_hyp=10, dtype=np.float32)
+        row = ap.run_case_on(nm, oracle, P[:n].astype(np.float64), lay, 40, "cfg2", "closed_loop", nthreads=16, tight=n_tight > 0,
+                             audit=True, audit_max=10 ** 6, tight_audit=False, n_tight=n_tight or None, polish=False)
+        print(json.dumps(digest(row, "cfg2", fam)), flush=True)
+        continue
+    for wl in ("cfg1", "cfg2"):
+        row = ap.run_case(nm, oracle, wl, fam, n=n, nthreads=16, tight=n_tight > 0, audit=True, audit_max=10 ** 6, tight_audit=False,
+                          n_tight=n_tight or None)
+        print(json.dumps(digest(row, wl, fam)), flush=True)
