@@ -40,6 +40,9 @@ print(json.dumps({
     "lockstep_steps": len(res.solve_ms), "scenario_steps": scen_steps,
     "solve_kernel_ms_total": float(np.sum(res.solve_ms)), "solve_kernel_share": float(np.sum(res.solve_ms)) * 1e-3 / el,
     "solve_kernel_ms_per_step": [round(float(x), 2) for x in res.solve_ms[:6]] + ["..."] + [round(float(x), 2) for x in res.solve_ms[-3:]],
+    # every lock-step: scenarios still running, kernel time of their solves, solves/s of that step
+    "per_step": [{"step": kt, "running": int((res.steps > kt).sum()), "solve_ms": round(float(ms), 2),
+                  "solves_per_s": round(float((res.steps > kt).sum()) / (float(ms) * 1e-3))} for kt, ms in enumerate(res.solve_ms)],
     "dispatch": "longest first by the previous time step's evaluation counts" if ev.dispatch_by_history and B >= ev.dispatch_min_batch else "index order",
     "complete_rate": float(res.complete.mean()), "collision_rate": float((res.collision & ~res.complete).mean()),
     "mean_steps": float(res.steps.mean())}))
