@@ -447,6 +447,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                     step_done = true;
                 } else {
                     request_candidates(0);
+                    NMPC_STAMP(I, 15); // (diagnostic: a round without an acceptable candidate -- replay + the next requests + barrier A)
                     phase = SP_LSN;
                     continue;
                 }
@@ -467,6 +468,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 step_done = true;
             } else {
                 request_candidates(0);
+                NMPC_STAMP(I, 15);
                 continue; // stay in SP_LSN
             }
         } else { // SP_OUTER

@@ -21,6 +21,7 @@ names = {0: "solver -> eval entry", 1: "rollout", 2: "polygons+fleet", 3: "segme
          12: "L-BFGS update", 13: "L-BFGS direction (two-loop recursion / compact form)"}
 print(f"W={W}: {ms:.2f} ms, {n_it} inner iterations, {ms*1e-3*2.4e9/n_it:.0f} cycles/iter (wavefront 0's stamps below, ticks per iteration)")
 names[14] = "requests formed + barrier (A) [then: loop head + evaluation prologue = slot 0]"
-tot = prof[:15].sum()
-for i in range(15):
+names[15] = "round without an acceptable candidate: replay + next requests + barrier (A)"
+tot = prof[:16].sum()
+for i in range(16):
     print(f"  {names[i]:34s} {prof[i]/n_it:8.0f}  {prof[i]/tot*100:5.1f}%")
