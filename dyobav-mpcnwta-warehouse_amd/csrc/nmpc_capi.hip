@@ -427,7 +427,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void rank_hist_kernel(const T* resume, const int* status, int B, int* hist, int key)
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b < B) atomicAdd(&hist[rank_bucket(resume, status, b, key)], 1);
+    const int q = b < B ? rank_bucket(resume, status, b, key) : -1;
+    // Bucket 0 -- the instances that finished in the pilot, half of a `passing`-type batch -- is counted once per wavefront:
+    // 34 k atomics on one address took 0.41 ms here and again in the scatter (profiles/r05_cfg2_passing_kernel_timeline.txt).
+    const unsigned long long m0 = __ballot(q == 0);
+    if (q > 0) atomicAdd(&hist[q], 1);
+    else if (q == 0 && (int)(threadIdx.x & 63) == __ffsll((long long)m0) - 1) atomicAdd(&hist[0], __popcll(m0));
 }
 // offs[q] = number of instances in buckets above q (one workgroup of kRankBuckets threads; reversed inclusive scan)
 // (the counters are left zeroed for the next ranking: no memset between launches)
@@ -451,7 +456,17 @@ template <typename T>
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const T* resume, const int* status, int B, int* offs, int* order, int key)
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b < B) order[atomicAdd(&offs[rank_bucket(resume, status, b, key)], 1)] = b;
+    const int q = b < B ? rank_bucket(resume, status, b, key) : -1;
+    const unsigned long long m0 = __ballot(q == 0);
+    if (q > 0) {
+        order[atomicAdd(&offs[q], 1)] = b;
+    } else if (q == 0) { // one atomic per wavefront for the finished instances (see rank_hist_kernel)
+        const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)m0) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&offs[0], __popcll(m0));
+        base = __shfl(base, leader);
+        order[base + __popcll(m0 & ((1ull << lane) - 1ull))] = b;
+    }
 }
 
 // Polish: fp64 copies of the selected instances' parameters and of the main solve's (u, y, c) / results back into the
