@@ -293,6 +293,12 @@ class BatchEvaluator:
         self.hcount = self.hcount + moving.long()
 
     # ---------------------------------------------------------------------------------------------------------
+    def _solve(self, hs, Pa, nA, Ua, u0, ya, y_is_input, info):
+        """The MPC solves of one time step: parameters ``Pa[nA, np]`` -> controls ``Ua[nA, 2N]``, multipliers ``ya`` in / out
+        (device tensors; main_base.py:308-311 per scenario). One overridable call, so that a checker can drive the same
+        closed loop with another solver (tests/test_gpu_closed_loop.py puts the CPU oracle here)."""
+        hs.solve_raw(self.dt, Pa, nA, Ua, u0=u0, y=ya, y_is_input=y_is_input, info=info, sync=False)
+
     def run(self, max_steps: int = 120, record: Optional[list] = None) -> EvaluationResult:
         """``record``: if a list, one dict per time step is appended with host copies of what the step saw and
         produced (robot, humans, P, y_in, U) -- for step-by-step checks against the sequential API; costs a
@@ -387,7 +393,7 @@ class BatchEvaluator:
                 info = self._info[:nA]
             else:
                 info = None
-            hs.solve_raw(self.dt, Pa, nA, Ua, u0=u0, y=ya, y_is_input=kt > 0, info=info, sync=False)
+            self._solve(hs, Pa, nA, Ua, u0, ya, kt > 0, info)
             if info is not None:
                 if full:
                     self._evals.copy_(info[:, 4])
@@ -474,7 +480,7 @@ class BatchEvaluator:
                 info = self._info[:nA]
             else:
                 info = None
-            hs.solve_raw(self.dt, Pa, nA, Ua, u0=u0, y=ya, y_is_input=kt > 0, info=info, sync=False)
+            self._solve(hs, Pa, nA, Ua, u0, ya, kt > 0, info)
             if info is not None:
                 if full:
                     self._evals.copy_(info[:, 4])
