@@ -156,8 +156,8 @@ def test_closed_loop_driven_by_the_oracle_against_the_kernels():
             Ua[:nA].copy_(torch.as_tensor(np.array([o[0] for o in out]), dtype=Ua.dtype))
             ya[:nA].copy_(torch.as_tensor(np.array([o[1] for o in out]), dtype=ya.dtype))
 
-    def drive(cls, reassoc=False):
-        ev = cls(copy.copy(cfg), dtype=np.float64, human_stagger=0.2, seed=9, n_hyp=10, compact=False, **sc)
+    def drive(cls, reassoc=False, dtype=np.float64):
+        ev = cls(copy.copy(cfg), dtype=dtype, human_stagger=0.2, seed=9, n_hyp=10, compact=False, **sc)
         ev.reassoc = reassoc
         rec = []
         res = ev.run(max_steps=T, record=rec)
@@ -165,6 +165,8 @@ def test_closed_loop_driven_by_the_oracle_against_the_kernels():
         return res, rec
 
     (r_hip, c_hip), (r_orc, c_orc), (r_twn, c_twn) = drive(BatchEvaluator), drive(OracleDriven), drive(OracleDriven, True)
+    cfg.lip_eps_f32 = cfg.lip_delta_f32 = LIP_STEP
+    r_h32, c_h32 = drive(BatchEvaluator, dtype=np.float32)     # the headline dtype in the loop (its own fp32 states and parameters)
     # the first time step: identical parameters on all three sides; the first actions as in the one-shot protocol
     assert np.array_equal(c_hip[0]["P"], c_orc[0]["P"]) and np.array_equal(c_orc[0]["P"], c_twn[0]["P"])
     du0_hip = np.abs(c_hip[0]["U"] - c_orc[0]["U"]).max(axis=1)
@@ -185,6 +187,8 @@ def test_closed_loop_driven_by_the_oracle_against_the_kernels():
     print("closed loop HIP  vs oracle:", s_hip)
     print("closed loop twin vs oracle:", s_twn)
     print("closed loop HIP  vs twin  :", summary(r_hip, c_hip, r_twn, c_twn))
+    s_h32 = summary(r_h32, c_h32, r_orc, c_orc)
+    print("closed loop HIP fp32 vs oracle:", s_h32, "| complete, collision:", int(r_h32.complete.sum()), int(r_h32.collision.sum()))
     print("outcomes (complete, collision): HIP", int(r_hip.complete.sum()), int(r_hip.collision.sum()),
           "| oracle", int(r_orc.complete.sum()), int(r_orc.collision.sum()), "| twin", int(r_twn.complete.sum()), int(r_twn.collision.sum()))
     # Most first-step solves of this distribution end at their iteration caps (nobody is near yet, but the 14 map boxes and the
@@ -196,3 +200,7 @@ def test_closed_loop_driven_by_the_oracle_against_the_kernels():
     assert s_hip["median_max_pos_diff"] <= 2.0 * s_twn["median_max_pos_diff"] + 0.05
     assert abs(int(r_hip.complete.sum()) - int(r_orc.complete.sum())) <= max(3, abs(int(r_twn.complete.sum()) - int(r_orc.complete.sum())) + 2)
     assert r_hip.complete.sum() >= 0.6 * B        # (the loop does what it is for: most robots arrive)
+    # ... and so is the fp32 loop (the dtype the throughput is quoted in), whose states and parameters are its own from step 0
+    assert s_h32["same_outcome"] >= s_twn["same_outcome"] - 0.15
+    assert s_h32["median_max_pos_diff"] <= 2.0 * s_twn["median_max_pos_diff"] + 0.05
+    assert abs(int(r_h32.complete.sum()) - int(r_orc.complete.sum())) <= max(3, abs(int(r_twn.complete.sum()) - int(r_orc.complete.sum())) + 2)
