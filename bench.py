@@ -521,7 +521,7 @@ def secondary_workloads(env: Env, args) -> list:
             continue
         nohint = note == "nohint"
         if nohint:
-            note = "configs[1] WITHOUT the capacity hint: all 15 obstacle rows of the shipped yaml provisioned (14-slot register table)"
+            note = "configs[1] WITHOUT the capacity hint: all 15 obstacle rows of the shipped yaml provisioned (6-slot register table since round 5; the 14-slot one before)"
         r = run_workload(env, workload, family, dtype, steps, warmup, batch=batch, dispatch_hint=hint, polish=polish,
                          capacity_hint=not nohint)
         r.pop("_host")

@@ -93,6 +93,9 @@ struct Layout {
     long long ws_stride;  // workspace elements per instance (glb only)
 };
 
+#ifndef NMPC_MID_SLOTS
+#define NMPC_MID_SLOTS 1 // offer the 6-slot register-table kernels (13..18 provisioned rows)
+#endif
 #ifndef NMPC_SPEC_WPE_F32
 #define NMPC_SPEC_WPE_F32 3 // wavefronts per SIMD the fp32 latency kernel is compiled for (caps VGPRs at 168)
 #endif
@@ -106,7 +109,9 @@ int round4(int x) { return (x + 3) & ~3; }
 // exchange area of a latency-kernel workgroup of W wavefronts (nmpc_spec.h: xch + command area)
 int spec_xch_elems(int W) { return round4(W * (2 * 64 + 4) + 2 * 64 * W + 8); } // (+ 8 command scalars: c, 1/max(c,1), flags, exit, gamma, 1/gamma)
 
-constexpr int kRegSlotsSmall = 4, kRegSlotsLarge = 14; // compiled register-table sizes (rows = 3 x slots)
+constexpr int kRegSlotsSmall = 4, kRegSlotsMid = 6, kRegSlotsLarge = 14; // compiled register-table sizes (rows = 3 x slots)
+// (Mid, round 5: 13..18 provisioned rows -- the reference's shipped yaml provisions 15 -- at the 168-register budget of the 4-slot
+//  kernels, three wavefronts per SIMD / four per instance in latency mode, instead of the 256-register 14-slot kernels)
 constexpr int kRegSlotsCoop = 12; // one lane per step: 8 cooperating wavefronts (2 per SIMD, 256 registers each) x 12 slots in
                                   // registers (96 rows; 144 with helper lanes, below); the rows beyond those in LDS
 constexpr int kCoopRegWaves = 8;
@@ -140,6 +145,7 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false,
     L.rs = 0;
     if (elem_size == 4 && c.reg_table >= 0 && N <= 21 && 64 / N >= 3 && cap > 0) {
         if (cap <= 3 * kRegSlotsSmall) L.rs = kRegSlotsSmall;
+        else if (cap <= 3 * kRegSlotsMid && NMPC_MID_SLOTS) L.rs = kRegSlotsMid;
         else if (cap <= 3 * kRegSlotsLarge) L.rs = kRegSlotsLarge;
     }
     if (elem_size == 8 && reg64 && c.reg_table >= 0 && N <= 21 && 64 / N >= 3 && cap > 3 * kRegSlotsSmall && cap <= 3 * kRegSlotsLarge)
@@ -714,8 +720,12 @@ template <typename T>
 SolveFn<T> pick_solve(int lps, bool glb, int rs = 0, int only = 1)
 {
     if constexpr (sizeof(T) == 4)
+    {
         if (rs == kRegSlotsSmall && lps == 3 && !glb)
             return only == 2 ? solve_kernel<T, 3, false, kRegSlotsSmall, 2> : solve_kernel<T, 3, false, kRegSlotsSmall, 1>;
+        if (rs == kRegSlotsMid && lps == 3 && !glb)
+            return only == 2 ? solve_kernel<T, 3, false, kRegSlotsMid, 2> : solve_kernel<T, 3, false, kRegSlotsMid, 1>;
+    }
     if (rs == kRegSlotsLarge && lps == 3 && !glb)
         return only == 2 ? solve_kernel<T, 3, false, kRegSlotsLarge, 2> : solve_kernel<T, 3, false, kRegSlotsLarge, 1>;
     if (glb) return lps == 3 ? solve_kernel<T, 3, true> : lps == 2 ? solve_kernel<T, 2, true> : solve_kernel<T, 1, true>;
@@ -727,6 +737,8 @@ SolveFn<T> pick_solve_spec(int lps, bool glb, int rs = 0, int only = 1)
     if constexpr (sizeof(T) == 4) {
         if (rs == kRegSlotsSmall && lps == 3 && !glb)
             return only == 2 ? solve_spec_kernel<T, 3, false, kRegSlotsSmall, 2> : solve_spec_kernel<T, 3, false, kRegSlotsSmall, 1>;
+        if (rs == kRegSlotsMid && lps == 3 && !glb)
+            return only == 2 ? solve_spec_kernel<T, 3, false, kRegSlotsMid, 2> : solve_spec_kernel<T, 3, false, kRegSlotsMid, 1>;
         if (rs == kRegSlotsLarge && lps == 3 && !glb)
             return only == 2 ? solve_spec_kernel<T, 3, false, kRegSlotsLarge, 2> : solve_spec_kernel<T, 3, false, kRegSlotsLarge, 1>;
     }
@@ -747,8 +759,12 @@ template <typename T>
 EvalFn<T> pick_eval(int lps, bool glb, int rs = 0, int only = 1)
 {
     if constexpr (sizeof(T) == 4)
+    {
         if (rs == kRegSlotsSmall && lps == 3 && !glb)
             return only == 2 ? eval_kernel<T, 3, false, kRegSlotsSmall, 2> : eval_kernel<T, 3, false, kRegSlotsSmall, 1>;
+        if (rs == kRegSlotsMid && lps == 3 && !glb)
+            return only == 2 ? eval_kernel<T, 3, false, kRegSlotsMid, 2> : eval_kernel<T, 3, false, kRegSlotsMid, 1>;
+    }
     if (rs == kRegSlotsLarge && lps == 3 && !glb)
         return only == 2 ? eval_kernel<T, 3, false, kRegSlotsLarge, 2> : eval_kernel<T, 3, false, kRegSlotsLarge, 1>;
     if (glb) return lps == 3 ? eval_kernel<T, 3, true> : lps == 2 ? eval_kernel<T, 2, true> : eval_kernel<T, 1, true>;

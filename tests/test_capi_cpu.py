@@ -103,9 +103,14 @@ def test_layout_bookkeeping_without_a_device():
     kernels of that fallback index cap * (N + 1) rows of the workspace."""
     cfg = nm.default_config_struct()
     li = nm.layout_info(cfg)
-    assert li.np == 2778 and li.reg_slots_f32 == 14 and not li.global_table_f32 and li.table_entries_f32 == 3 * 14   # (t = 0 rows of the register table, padded with dummy rows to 3 x slots)
+    # (15 rows of the shipped yaml: the 6-slot register table since round 5; t = 0 rows padded with dummy rows to 3 x slots)
+    assert li.np == 2778 and li.reg_slots_f32 == 6 and not li.global_table_f32 and li.table_entries_f32 == 3 * 6
     cfg.max_active_dynobs = 10
     assert nm.layout_info(cfg).reg_slots_f32 == 4
+    cfg = nm.default_config_struct()
+    cfg.Ndynobs = 40                                    # BASELINE configs[2]: 4 x 10 hypotheses -> the 14-slot table
+    li = nm.layout_info(cfg)
+    assert li.reg_slots_f32 == 14 and li.table_entries_f32 == 3 * 14
     cfg = nm.default_config_struct()
     cfg.N_hor, cfg.Ndynobs = 40, 160                    # BASELINE configs[4]: 236 KB table -> global workspace
     li = nm.layout_info(cfg)

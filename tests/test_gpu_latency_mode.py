@@ -74,16 +74,24 @@ def test_latency_mode_other_dimensions():
 def test_automatic_choice_follows_batch_size():
     """latency_waves = 0: batches of at most one workgroup per CU get six wavefronts per instance (fp32, 4-slot register
     table), small batches four (round 4: with the long instances started first the faster line search wins over what stays
-    resident together; 2 with the 14-slot register table, whose kernels run two wavefronts per SIMD), mid-size batches 2,
-    large ones the throughput kernel (info[7] = wavefronts per instance, 0 = throughput kernel)."""
+    resident together) -- also with the 15 rows of the shipped yaml and no capacity hint, which run on the 6-slot register
+    table at the same register budget (round 5); 2 with the 14-slot register table (more than 18 rows), whose kernels run two
+    wavefronts per SIMD; mid-size batches 2, large ones the throughput kernel (info[7] = wavefronts per instance, 0 =
+    throughput kernel)."""
     P_small = nm.scenarios.make_batch(32, seed=37)
-    for hint, dtype, expect in ((10, np.float32, 6), (0, np.float32, 2), (0, np.float64, 4)):
+    for hint, dtype, expect in ((10, np.float32, 6), (0, np.float32, 4), (0, np.float64, 4)):
         cfg = nm.default_config_struct()
         cfg.latency_waves = 0
         cfg.max_active_dynobs = hint
         with nm.Handle(cfg) as h:
             small = h.solve(P_small.astype(dtype), dtype=dtype)
         assert (small["info"][:, 7] == expect).all(), (hint, dtype, small["info"][0, 7])
+    lay24 = nm.scenarios.ParamLayout(20, 10, 10, 24)
+    cfg = nm.default_config_struct()
+    cfg.latency_waves, cfg.Ndynobs = 0, 24
+    with nm.Handle(cfg) as h:
+        r24 = h.solve(nm.scenarios.make_batch(32, lay24, seed=37, n_ped=4, n_hyp=5).astype(np.float32), dtype=np.float32)
+    assert (r24["info"][:, 7] == 2).all(), r24["info"][0, 7]
     cfg = nm.default_config_struct()
     cfg.latency_waves = 0
     cfg.max_active_dynobs = 10

@@ -38,7 +38,7 @@ def _on_path_batch(lay, B, seed, n_ped, n_hyp, rotate=False):
     return P
 
 
-@pytest.mark.parametrize("n_ped,n_hyp,slots", [(2, 5, 4), (4, 10, 14), (1, 1, 4), (7, 6, 14)])
+@pytest.mark.parametrize("n_ped,n_hyp,slots", [(2, 5, 4), (4, 10, 14), (1, 1, 4), (7, 6, 14), (3, 5, 6), (3, 6, 6)])
 def test_axis_aligned_variant_against_oracle_and_general_kernel(n_ped, n_hyp, slots):
     lay = ParamLayout(N=20, Ndyn=max(15, n_ped * n_hyp))
     B = 24

@@ -33,11 +33,20 @@ def test_fp32_throughput_kernels_do_not_spill(resources):
     # (angle = 0, main_base.py:302) take and what bench.py times -- and <.., 2> = the general (rotated-ellipse) path alone.
     # The axis-aligned members must be free of VGPR spills and scratch; the general path of the 14-slot kernel keeps a few
     # table values in scratch (written once in load(), read once per evaluation).
+    # (Round 5: the 6-slot kernels -- 13..18 provisioned rows, the shipped yaml's 15 -- hold half as many table rows again at
+    #  the 4-slot kernels' budget of 168 registers (three wavefronts per SIMD): 6 / 21 VGPRs in scratch, and still +18 % at
+    #  B = 65 536 and +35 % at B = 1024 over the 256-register 14-slot kernels they replace there, tools/ab_nohint.py.)
     for name, r in _sel(resources, r"^solve_kernel<float").items():
         general = re.search(r"<float, 3, false, (4|14), 2>", name) is not None
+        mid = re.search(r"<float, 3, false, 6, (1|2)>", name)
         assert r["sgpr_spill"] <= 16, (name, r)
-        assert r["vgpr_spill"] <= (16 if general else 0) and r["scratch"] <= (48 if general else 0), (name, r)
+        if mid:
+            lim = (8, 32) if mid.group(1) == "1" else (24, 96)
+            assert r["vgpr_spill"] <= lim[0] and r["scratch"] <= lim[1], (name, r)
+        else:
+            assert r["vgpr_spill"] <= (16 if general else 0) and r["scratch"] <= (48 if general else 0), (name, r)
     assert "solve_kernel<float, 3, false, 14, 1>" in resources and "solve_kernel<float, 3, false, 4, 1>" in resources
+    assert "solve_kernel<float, 3, false, 6, 1>" in resources
 
 
 def test_register_budgets_of_the_kernel_variants(resources):
@@ -46,6 +55,8 @@ def test_register_budgets_of_the_kernel_variants(resources):
         assert resources[f"solve_kernel<float, 3, false, 14, {only}>"]["vgpr"] <= 256
         assert resources[f"solve_kernel<float, 3, false, 4, {only}>"]["vgpr"] <= 168
         assert resources[f"solve_spec_kernel<float, 3, false, 4, {only}>"]["vgpr"] <= 168
+        assert resources[f"solve_kernel<float, 3, false, 6, {only}>"]["vgpr"] <= 168
+        assert resources[f"solve_spec_kernel<float, 3, false, 6, {only}>"]["vgpr"] <= 168
     assert resources["solve_kernel<float, 3, false, 0, 0>"]["vgpr"] <= 168
     for name, r in _sel(resources, r"^solve_spec_kernel<float, \d, (true|false), 0, 0>").items():
         assert r["vgpr"] <= 168 and r["vgpr_spill"] == 0, (name, r)
@@ -63,7 +74,8 @@ def test_fp32_latency_and_cooperative_kernels_spill_little(resources):
         #  scalar load; with the candidates' FBE formed by the wavefront that evaluated them +1.8 % on configs[1])
         assert r["sgpr_spill"] <= 52, (name, r)
         # (general path of the register-table variants: up to 23 VGPRs in scratch; the axis-aligned members: 0 / 9 dwords)
-        assert r["scratch"] <= (96 if general else 40 if axis else 0), (name, r)
+        mid = re.search(r"<float, 3, false, 6, (1|2)>", name)       # (6-slot kernels: 16 / 32 VGPRs in scratch, see above)
+        assert r["scratch"] <= ((72 if mid.group(1) == "1" else 168) if mid else 96 if general else 40 if axis else 0), (name, r)
     sel = _sel(resources, r"solve_coop(_reg)?_kernel<(float|true|false)")
     assert any("coop_reg" in n for n in sel)          # (the on-chip kernels are named <true> / <false>: they must not drop out)
     for name, r in sel.items():
