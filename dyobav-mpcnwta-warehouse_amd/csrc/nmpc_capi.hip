@@ -857,7 +857,8 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
         // on (B = 512) six or eight wavefronts cost more than they bring
         // (profiles/r04_exp_cfg1_batch_size_and_up_to_8_wavefronts.txt). Same results, bit for bit.
         // (the 4-slot register table only: what was measured, and what nmpc_hip.h documents -- ADVICE r4)
-        if (sizeof(T) == 4 && L.rs == kRegSlotsSmall && !L.glb && 4 * B <= h->n_simd) lw = kSpecWavesWide;
+        // (the 6-slot table, same register budget: measured too -- B = 64 / 256: 22.98 -> 21.37 / 18.12 -> 16.96 ms, tools/exp_mid_w6.py)
+        if (sizeof(T) == 4 && (L.rs == kRegSlotsSmall || L.rs == kRegSlotsMid) && !L.glb && 4 * B <= h->n_simd) lw = kSpecWavesWide;
         // Large batches whose LDS tables allow only a few workgroups per CU (e.g. 40 active obstacle rows: 35 KB,
         // 4 per CU = one wavefront per SIMD): the wavefronts of a latency-kernel workgroup SHARE the instance's
         // tables, so W of them fill the SIMDs that the throughput kernel leaves empty (measured on configs[2]:

@@ -72,14 +72,14 @@ def test_latency_mode_other_dimensions():
 
 
 def test_automatic_choice_follows_batch_size():
-    """latency_waves = 0: batches of at most one workgroup per CU get six wavefronts per instance (fp32, 4-slot register
+    """latency_waves = 0: batches of at most one workgroup per CU get six wavefronts per instance (fp32, 4- or 6-slot register
     table), small batches four (round 4: with the long instances started first the faster line search wins over what stays
     resident together) -- also with the 15 rows of the shipped yaml and no capacity hint, which run on the 6-slot register
     table at the same register budget (round 5); 2 with the 14-slot register table (more than 18 rows), whose kernels run two
     wavefronts per SIMD; mid-size batches 2, large ones the throughput kernel (info[7] = wavefronts per instance, 0 =
     throughput kernel)."""
     P_small = nm.scenarios.make_batch(32, seed=37)
-    for hint, dtype, expect in ((10, np.float32, 6), (0, np.float32, 4), (0, np.float64, 4)):
+    for hint, dtype, expect in ((10, np.float32, 6), (0, np.float32, 6), (0, np.float64, 4)):
         cfg = nm.default_config_struct()
         cfg.latency_waves = 0
         cfg.max_active_dynobs = hint
