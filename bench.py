@@ -68,7 +68,12 @@ def measured_traffic(workload, dtype, batch, family="toward_robot"):
         if rec.get("workload") == workload and rec.get("dtype") == dtype and rec.get("batch") == batch and \
                 rec.get("family", "toward_robot") == family:
             best = rec
-    return None if best is None else float(best["hbm_bytes_per_launch"])
+    if best is None:
+        return None
+    # (profiles/rNN_cfg4_f64_traffic.json holds both members of the streamed-table kernel pair: the compressed table is the
+    #  one the reference's axis-aligned inputs take)
+    val = best.get("hbm_bytes_per_launch", (best.get("compressed") or {}).get("hbm_bytes_per_launch"))
+    return None if val is None else float(val)
 
 
 def flops_forward(N, Nother, Nstc, Ndyn):

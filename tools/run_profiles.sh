@@ -3,7 +3,7 @@
 # Usage (from the repo root, inside gpurun): bash tools/run_profiles.sh r05
 set -u
 R=$(pwd); RN=${1:-r05}; OUT=$R/gpurun_out/$RN; mkdir -p $OUT
-RNUM=$(echo $RN | sed 's/^r0*//')
+RNUM=$(echo $RN | sed 's/^r0*//; s/[^0-9].*$//')
 export TMPDIR=/tmp
 cd /tmp
 B="python3 $R/bench.py"
