@@ -159,3 +159,77 @@ def test_config0_scenario_0_with_the_warehouse_static_map(cases):
     assert r["reached_goal"] and r["max_penetration_into_an_inflated_polygon_m"] < 0.15, r
     assert r["min_pedestrian_distance_m"] > ev.HUMAN_SIZE, r
     assert r["steps"] < 160 and r["mean_ms"] < 100.0          # (the reference's budget per step: max_solver_time = 0.1 s)
+
+
+def test_config0_scenario_0_driven_by_the_oracle_against_the_kernels(cases):
+    """BASELINE configs[0] as a system-level parity statement: the scenario_0 closed loop with the warehouse's static map,
+    through the drop-in interface (MpcInterface -> TrajectoryTracker.run_step -> solver.run(p), multipliers carried between
+    calls as OpEn's binding does), driven once by the HIP kernels and once by the CPU oracle put in the tracker's solver
+    slot -- and by the oracle's re-associated twin as the yardstick. Same options on both sides (what ``make_config``
+    derives from mpc_default.yaml), no wall-clock budget."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    import bench_scenario0
+    import oracle
+    from dyobav_mpcnwta_warehouse_amd.solver import OptimizerSolution
+
+    class OracleSolver:
+        """solver().run(p) backed by the oracle; keeps the multipliers of the previous call like solver.Solver does"""
+
+        def __init__(self, tracker, reassoc):
+            c = tracker.solver.config                     # the configuration the HIP solver of this tracker was created with
+            self.pr = oracle.Problem(c.N_hor, c.Nother, c.Nstcobs, c.Ndynobs, c.ts, c.lin_vel_min, c.lin_vel_max, c.ang_vel_max,
+                                     c.lin_acc_min, c.lin_acc_max, c.ang_acc_max, c.vehicle_width, c.vehicle_margin, c.social_margin)
+            self.op = oracle.Options(tolerance=c.tolerance, initial_tolerance=c.initial_tolerance, delta_tolerance=c.delta_tolerance,
+                                     max_outer=c.max_outer_iterations, max_inner=c.max_inner_iterations, lbfgs_mem=c.lbfgs_memory,
+                                     initial_penalty=c.initial_penalty, penalty_update=c.penalty_update_factor,
+                                     inner_tol_update=c.inner_tolerance_update_factor, sufficient_decrease=c.sufficient_decrease_coeff,
+                                     lip_delta=c.lip_delta_f64, lip_eps=c.lip_eps_f64, cbfgs_alpha=c.cbfgs_alpha,
+                                     cbfgs_eps=c.cbfgs_epsilon, sy_eps=c.sy_epsilon, akkt_form=c.akkt_form)
+            self.reassoc = reassoc
+            self.y = None
+            self.n_converged = self.n_calls = 0
+            tracker.solver.close() if hasattr(tracker.solver, "close") else None
+
+        def run(self, p, initial_guess=None, initial_lagrange_multipliers=None, initial_penalty=None):
+            u, y, res = oracle.solve(self.pr, self.op, np.asarray(p, dtype=np.float64).ravel(), u0=initial_guess,
+                                     y0=self.y if initial_lagrange_multipliers is None else initial_lagrange_multipliers, reassoc=self.reassoc)
+            self.y = y
+            self.n_calls += 1
+            self.n_converged += int(res["status"] == 0)
+            st = {0: "Converged", 1: "NotConvergedIterations", 2: "NotConvergedOutOfTime"}.get(int(res["status"]), "NotFiniteComputation")
+            return OptimizerSolution(exit_status=st, num_outer_iterations=int(res["outer_iters"]), num_inner_iterations=int(res["inner_iters"]),
+                                     last_problem_norm_fpr=0.0, f1_infeasibility=0.0, f2_norm=0.0, solve_time_ms=0.0, penalty=0.0,
+                                     solution=[float(v) for v in u], lagrange_multipliers=[float(v) for v in y], cost=float(res["cost"]))
+
+    made = []
+
+    def swap(reassoc):
+        def f(tracker):
+            made.append(OracleSolver(tracker, reassoc))
+            return made[-1]
+        return f
+
+    os.environ["SCENARIO0_TRAJ"] = "1"
+    try:
+        r_hip = bench_scenario0.run(max_steps=160, with_map=True)
+    finally:
+        os.environ.pop("SCENARIO0_TRAJ")
+    r_orc = bench_scenario0.run(max_steps=160, with_map=True, swap_solver=swap(False))
+    r_twn = bench_scenario0.run(max_steps=160, with_map=True, swap_solver=swap(True))
+
+    def dist(a, b):
+        ta, tb = np.array(a["trajectory"]), np.array(b["trajectory"])
+        n = min(len(ta), len(tb))
+        return float(np.linalg.norm(ta[:n, :2] - tb[:n, :2], axis=1).max()), n
+    d_hip, n_hip = dist(r_hip, r_orc)
+    d_twn, n_twn = dist(r_twn, r_orc)
+    print("scenario_0 + map: steps HIP %d / oracle %d / twin %d; largest distance between the robots along the run: HIP vs oracle %.3e m (%d steps), "
+          "twin vs oracle %.3e m; oracle converged %d / %d solves" % (r_hip["steps"], r_orc["steps"], r_twn["steps"], d_hip, n_hip, d_twn,
+                                                                       made[0].n_converged, made[0].n_calls))
+    for r in (r_hip, r_orc, r_twn):
+        assert r["reached_goal"] and r["min_pedestrian_distance_m"] > ev.HUMAN_SIZE, r
+    assert abs(r_hip["steps"] - r_orc["steps"]) <= max(2, abs(r_twn["steps"] - r_orc["steps"]) + 1)
+    # the kernels are no further from the oracle than its own re-association is (a benign scenario: most solves converge, the
+    # loops stay together to within centimetres)
+    assert d_hip <= max(3 * d_twn, 0.05), (d_hip, d_twn)

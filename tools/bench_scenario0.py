@@ -32,7 +32,10 @@ def penetration(p, quads):
     return float(d[inside].min(axis=1).max())
 
 
-def run(max_steps=160, with_map=True, second_pedestrian=False):
+def run(max_steps=160, with_map=True, second_pedestrian=False, swap_solver=None):
+    """``swap_solver``: callable(tracker) -> object with ``run(parameters)`` that takes the place of the tracker's solver
+    (tests/test_gpu_evaluate_reference.py puts the CPU oracle there to compare closed loops); the returned record then also
+    carries the robot's trajectory."""
     cases = json.load(open(os.path.join(ROOT, "tests", "golden", "evaluate_cases.json")))
     sc = cases["scenario_0"]
     node = lambda k: tuple(sc["nodes_world"][str(k)])
@@ -44,6 +47,8 @@ def run(max_steps=160, with_map=True, second_pedestrian=False):
     mi = MpcInterface("mpc_default.yaml", start.copy(), types.SimpleNamespace(processed_obstacle_list=[list(map(tuple, q)) for q in polys]),
                       verbose=False)
     mi.update_global_path(robot_path)
+    if swap_solver is not None:
+        mi.traj_tracker.solver = swap_solver(mi.traj_tracker)
     h0 = np.array(sc["human_starts_world"][0])
     # the scenario's own pedestrian (main_base.py:38-44); a second one walking the other way is optional (far away if off)
     hstart = np.array([[h0, np.array(node(32)) + np.array([-2.0, 0.0]) if second_pedestrian else np.array([40.0, 40.0])]])
@@ -53,7 +58,7 @@ def run(max_steps=160, with_map=True, second_pedestrian=False):
                           np.array([[[50.0, 50.0], [49.0, 50.0], [49.0, 49.0], [50.0, 49.0]]]), dtype=np.float64)
     state = start.copy()
     goal = np.array(robot_path[-1])
-    times, min_ped, pen = [], np.inf, 0.0
+    times, min_ped, pen, traj = [], np.inf, 0.0, [state.copy()]
     for step in range(max_steps):
         rows = e._predict_cv().cpu().numpy()[0]
         mi.set_current_state(state)
@@ -61,6 +66,7 @@ def run(max_steps=160, with_map=True, second_pedestrian=False):
         actions, pred, cost, closest, refs = mi.run_step("work", rows.tolist(), True)
         times.append(time.perf_counter() - t0)
         state = mi.state.copy()
+        traj.append(state.copy())
         e._step_humans()
         peds = e.humans.cpu().numpy()[0]
         min_ped = min(min_ped, float(np.hypot(*(peds - state[:2]).T).min()))
@@ -73,7 +79,8 @@ def run(max_steps=160, with_map=True, second_pedestrian=False):
             "steps": len(times), "reached_goal": bool(np.abs(state[:2] - goal).max() <= 0.5), "mean_ms": float(t.mean()),
             "max_ms": float(t.max()), "median_ms": float(np.median(t)), "static_map_polygons": int(len(polys)) if with_map else 0,
             "pedestrians": 2 if second_pedestrian else 1,
-            "max_penetration_into_an_inflated_polygon_m": pen, "min_pedestrian_distance_m": min_ped, "final_state": state.tolist()}
+            "max_penetration_into_an_inflated_polygon_m": pen, "min_pedestrian_distance_m": min_ped, "final_state": state.tolist(),
+            **({"trajectory": np.array(traj).tolist()} if swap_solver is not None or os.environ.get("SCENARIO0_TRAJ") else {})}
 
 
 if __name__ == "__main__":
