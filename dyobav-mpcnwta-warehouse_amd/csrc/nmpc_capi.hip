@@ -182,14 +182,14 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false,
     L.lds_iflag = L.lds_fl + round4(c.Nother);         // int list: robots with a non-zero predicted position
     L.lds_hist = L.lds_iflag + round4(c.Ndynobs);  // int flags / compaction map (an int fits in a T)
     L.lds_rho = L.lds_hist + 4 * nmpc::kMem * nmpc::lbfgs_slot_stride(N); // L-BFGS ring: kMem slots x (N | 1) x (s_v, s_w, y_v, y_w)
-    L.lds_lbc = L.lds_rho + round4(2 * nmpc::kMem);    // rho[kMem], alpha[kMem]; then the compact-form workspace (16-B aligned)
-    L.lds_park = L.lds_lbc + round4(nmpc::lbfgs_compact_elems<float>(N)); // then the parking area(s)
+    L.lds_lbc = L.lds_rho + round4(2 * nmpc::kMem);    // rho[kMem], alpha[kMem]
+    L.lds_park = L.lds_lbc;                            // then the parking area(s) (16-B aligned)
     const int park_one = nmpc::kParkQuads * 4 * 64;    // elements per wavefront
     L.lds_total = L.lds_park + park_one;
-    // latency kernel: (only in a -DNMPC_SPEC_PARK=1 build, register-table variants: one parking area per wavefront of the
-    // largest workgroup -- ADVICE r4: sized for 4 while up to 8 could run), then the exchange area of W wavefronts (nmpc_spec.h):
-    // W result rows of 64 x 2 gradient entries + psi (padded to 132), the master's command area of 2 x 64 x W + 4 scalars
-    L.lds_xch = L.lds_park + ((NMPC_SPEC_PARK && L.rs) ? kSpecWavesMax * park_one : 0);
+    // latency kernel: the exchange area of W wavefronts (nmpc_spec.h) in place of the parking area (its solver vectors stay
+    // in registers): W result rows of 64 x 2 gradient entries + psi (padded to 132), the master's command area of
+    // 2 x 64 x W + 4 scalars
+    L.lds_xch = L.lds_park;
     L.lds_total_spec = L.lds_xch + spec_xch_elems(kSpecWavesMax);
     const int cw = coop_rs ? kCoopRegWaves : kSpecWaves;
     L.lds_xch_coop = L.lds_park + 2 * park_one; // cooperative kernels: two shared parking areas, used alternately

@@ -106,8 +106,6 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     T osv = 0, osw = 0, ogv = 0, ogw = 0, lb_gamma = 1;
     int lb_active = 0, lb_head = 0;
     int lb_first = 1; // (the wave-uniform flags are ints: a bool would live in an SGPR PAIR as a lane mask)
-    constexpr bool kCompactLb = (NMPC_LBFGS_COMPACT & 2) != 0; // the direction in compact form (nmpc_device.h, lbfgs_apply_compact)
-    int lb_new = 0;
     T dyn = 0, dyn_plus = 0, f2n = 0, f2n_plus = 0;
     int alm_iter = 0, inner_total = 0, outer = 1, status = 0;
     int num_iter = 0, lip_it = 0, nls = 0;
@@ -150,7 +148,6 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     };
     auto reset_cache = [&]() {
         lb_active = 0;
-        lb_new = 0;
         lb_first = true;
         rhs_ls = 0;
         tau = 1;
@@ -161,31 +158,6 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         gamma = 0;
         inv_gamma = 0;
         fbe_valid = false;
-    };
-
-    // cold solver vectors parked in LDS across the evaluation (see solve_instance); one area per wavefront
-#ifndef NMPC_SPEC_PARK
-#define NMPC_SPEC_PARK 0
-#endif
-    constexpr bool kSpecPark = NMPC_SPEC_PARK && RS > 0; // (the LDS-table variants fit their register budget without; measured)
-    Quad<T>* const parkp = reinterpret_cast<Quad<T>*>(lds + kp.lds_park) + wave * (kParkQuads * 64) + I.lane;
-    auto park = [&]() {
-        parkp[0 * 64] = Quad<T>{osv, osw, ogv, ogw};
-        parkp[1 * 64] = Quad<T>{gpv, gpw, sv, sw};
-        parkp[2 * 64] = Quad<T>{pv, pw, dv, dw};
-        parkp[3 * 64] = Quad<T>{hv, hw, fv, fw};
-        parkp[4 * 64] = Quad<T>{uv, uw, gv, gw};
-        asm volatile("" ::: "memory");
-    };
-    auto unpark = [&]() {
-        asm volatile("" ::: "memory");
-        const Quad<T> q0 = parkp[0 * 64], q1 = parkp[1 * 64], q2 = parkp[2 * 64], q3 = parkp[3 * 64],
-                      q4 = parkp[4 * 64];
-        osv = q0.a, osw = q0.b, ogv = q0.c, ogw = q0.d;
-        gpv = q1.a, gpw = q1.b, sv = q1.c, sw = q1.d;
-        pv = q2.a, pw = q2.b, dv = q2.c, dw = q2.d;
-        hv = q3.a, hw = q3.b, fv = q3.c, fw = q3.d;
-        uv = q4.a, uw = q4.b, gv = q4.c, gw = q4.d;
     };
 
     if (resuming) {
@@ -298,7 +270,6 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         }
         const T e_icd = ec == c ? inv_cdiv : T(1);
         if (do_eval) {
-            if (kSpecPark) park();
 #ifndef NMPC_SPEC_FLAT
 #define NMPC_SPEC_FLAT 1
 #endif
@@ -306,7 +277,6 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 I.template eval<true, NMPC_SPEC_FLAT != 0>(ev, ew, ec, e_icd, yv, yw, r_psi, r_f2, r_gv, r_gw);
             else
                 I.template eval<false, NMPC_SPEC_FLAT != 0>(ev, ew, ec, e_icd, yv, yw, r_psi, r_f2, r_gv, r_gw);
-            if (kSpecPark) unpark();
         }
         // The forward-backward envelope of a line-search candidate -- the left-hand side of its acceptance test -- by the
         // wavefront that evaluated it (round 5): psi - gamma/2 ||grad||^2 + ||gradient_step - Proj_U(gradient_step)||^2 / (2 gamma)
@@ -425,7 +395,6 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             if (anyb(cost_half > rhs && L < MAX_L) && lip_it < MAX_LIP) {
                 // gamma is halved: the speculative candidates (if any) are void, continue sequentially
                 lb_active = 0;
-                lb_new = 0;
                 lb_first = true;
                 L *= T(2);
                 gamma *= T(0.5);
@@ -685,7 +654,6 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 rho.set(lb_head, T(1) / ys);
                 lb_gamma = ys / I.dot2(nyv, nyw, nyv, nyw);
                 lb_active = lb_active + 1 < mem ? lb_active + 1 : mem;
-                lb_new = 1;
                 // (no barrier: the master alone writes and reads the ring, and a wavefront's LDS accesses stay in order)
             }
         }
@@ -698,11 +666,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             phase = SP_NOLS;
             continue;
         }
-        if constexpr (kCompactLb) {
-            lbfgs_apply_compact(I, hist, lds + cold_args<T>()->lds_lbc, rho, N, kk, mem, lb_head, lb_active, lb_new, lb_gamma, fv, fw, dv, dw);
-            lb_new = 0;
-        } else
-            lbfgs_apply(I, hist, rho, N, kk, mem, lb_head, lb_active, lb_gamma, fv, fw, dv, dw);
+        lbfgs_apply(I, hist, rho, N, kk, mem, lb_head, lb_active, lb_gamma, fv, fw, dv, dw);
         NMPC_STAMP(I, 13); // two-loop recursion
         if (!fbe_valid) {
             const T t1 = sv - hv, t2 = sw - hw;
