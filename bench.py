@@ -48,7 +48,12 @@ WORKLOADS = {
     "cfg4": ("long horizon N=40, 8 obs x 20 hypotheses, batch=8192, 1 MI355X",
              "cfg4_b8192_n40_8x20"),
 }
-CLOSED_LOOP_STEPS = (1, 8, 20)   # time steps at which the closed-loop family captures its parameter vectors
+CLOSED_LOOP_STEPS = (1, 8, 20)   # time steps at which the corridor closed-loop family captures its parameter vectors
+REFSCEN_STEPS = (2, 14, 26)      # ... and the reference-scenario family (runs of 45-95 steps: all scenarios still running; the
+                                 # scenario's own pedestrian meets the robot around steps 22-32, tools/bench_evaluate.py)
+HARVEST_STEPS = {"closed_loop": CLOSED_LOOP_STEPS, "refscen": REFSCEN_STEPS}
+HARVEST_FAMILY = {"closed_loop": "corridor", "refscen": "reference"}
+REFERENCE_TIME_CAP_US = 100_000  # config/mpc_fast.yaml max_solver_time (mpc_builder.py:189): the `_budget` rows
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
 
@@ -128,9 +133,25 @@ class Env:
         self.sync()
 
 
+def harvested_batch(env: Env, cfg, family: str, B: int, spec: dict, np_dtype):
+    """Parameter vectors harvested from the closed loop (scenarios.harvest_closed_loop), on the device; cached per
+    (family, B, dtype) so that the rows that time the same batch under other options (budget, polish) share one harvest."""
+    key = (family, B, np.dtype(np_dtype).name)
+    cache = env.__dict__.setdefault("harvest_cache", {})
+    if key not in cache:
+        t_h = time.perf_counter()
+        dP_h, step_of = env.nm.scenarios.harvest_closed_loop(cfg, B, steps=HARVEST_STEPS[family], seed=13 + env.rank,
+                                                             n_ped=spec["n_ped"], n_hyp=spec["n_hyp"], dtype=np_dtype,
+                                                             return_device=True, family=HARVEST_FAMILY[family])
+        cache[key] = (dP_h, {"capture_steps": {int(s_): int((step_of == s_).sum().item()) for s_ in env.torch.unique(step_of)},
+                             "seconds": time.perf_counter() - t_h, "scenarios": HARVEST_FAMILY[family]})
+    return cache[key]
+
+
 def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, warmup: int, batch=None,
                  latency_waves: int = 0, reg_table: int = 0, coop_waves: int = 0, dispatch_hint: bool = False,
-                 polish: bool = False, staged: int = 0, axis_aligned: int = 0, capacity_hint: bool = True) -> dict:
+                 polish: bool = False, staged: int = 0, axis_aligned: int = 0, capacity_hint: bool = True,
+                 budget: bool = False) -> dict:
     """Time `steps` passes of one workload (after `warmup` untimed ones); returns the measurements of this rank with
     the whole-job rate (max over ranks of the elapsed time)."""
     torch, dist, nm = env.torch, env.dist, env.nm
@@ -153,15 +174,12 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
     # capacity_hint = False: Ndynobs rows provisioned (the `_nohint` secondary row)
     cfg.max_active_dynobs = spec["n_ped"] * spec["n_hyp"] if capacity_hint else 0
     harvest = None
-    if family == "closed_loop":
+    if family in HARVEST_STEPS:
         # BASELINE configs[2] literally: "main_eva.py scenarios" -- parameter vectors harvested from the batched closed-loop
-        # evaluator (row f3) at these dimensions, a third each from an early, a mid-run and a near-the-goal time step
-        # (scenarios.harvest_closed_loop; tests/test_gpu_closed_loop.py runs the parity protocol on the same distribution)
-        t_h = time.perf_counter()
-        dP_h, step_of = nm.scenarios.harvest_closed_loop(cfg, B, steps=CLOSED_LOOP_STEPS, seed=13 + env.rank, n_ped=spec["n_ped"],
-                                                         n_hyp=spec["n_hyp"], dtype=np_dtype, return_device=True)
-        harvest = {"capture_steps": {int(s_): int((step_of == s_).sum().item()) for s_ in torch.unique(step_of)},
-                   "seconds": time.perf_counter() - t_h}
+        # evaluator (row f3) at these dimensions, a third each from three time steps of the runs. `refscen`: the reference's
+        # own scenario_0..2 on its warehouse map (scenarios.make_reference_scenarios); `closed_loop`: round 5's corridor
+        # family (tests/test_gpu_closed_loop.py runs the parity protocol on both distributions)
+        dP_h, harvest = harvested_batch(env, cfg, family, B, spec, np_dtype)
         P_host = dP_h[:4096].cpu().numpy()       # (what the CPU baseline / checksum of a --family closed_loop run sample)
     else:
         P_host = nm.scenarios.make_batch_chunked(B, layout, ped_mode=family, dtype=np_dtype, **spec)   # bounded host memory
@@ -171,6 +189,11 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
     cfg.polish = int(polish)
     cfg.staged = staged
     cfg.axis_aligned = axis_aligned
+    if budget:
+        # the reference's max_solver_time (0.1 s of ITS solver on a host core) as the deterministic evaluation budget
+        # (nmpc_config.max_evaluations; solver.evaluation_budget): a SECONDARY row, never the headline
+        from dyobav_mpcnwta_warehouse_amd.solver import evaluation_budget
+        cfg.max_evaluations = evaluation_budget(REFERENCE_TIME_CAP_US, layout.N, layout.Nother, layout.Nstc, layout.Ndyn)
     h = env.handle_factory(cfg)
     dev = env.device
     if dev == "cuda":
@@ -186,12 +209,29 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
     gathered = torch.empty(env.world * B, 2 * N, dtype=t_dtype, device=dev) if env.use_dist else None
     kernel_ms = []
 
+    gather_ms = []
+    cuda = dev == "cuda"
+    ev_g = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if (cuda and env.use_dist) else None
+
     def step(record):
         h.solve_raw(np_dtype, dP, B, dU, dcost, dstatus, diters, None, None, False, None, dinfo, sync=False)
         if env.use_dist:
-            dist.all_gather_into_tensor(gathered, dU)      # RCCL over xGMI: gather the results, nothing else
+            # RCCL over xGMI: gather the results, nothing else. Timed by HIP events on the stream the solve was enqueued on
+            # (torch's current stream = the handle's stream): what the gather itself costs, next to each rank's own time
+            t_g = time.perf_counter()
+            if ev_g and record:
+                ev_g[0].record()
+            dist.all_gather_into_tensor(gathered, dU)
+            if ev_g and record:
+                ev_g[1].record()
         if record:
             kernel_ms.append(h.last_kernel_ms())           # HIP events on the launch stream (syncs that stream)
+            if env.use_dist:
+                if ev_g:
+                    ev_g[1].synchronize()
+                    gather_ms.append(float(ev_g[0].elapsed_time(ev_g[1])))
+                else:                                      # (gloo stand-in of tests/test_bench_ranks_gloo.py: host clock)
+                    gather_ms.append((time.perf_counter() - t_g) * 1e3)
 
     if dispatch_hint:
         # nmpc_set_dispatch_order: longest first, ranked by the evaluation counts of an (untimed) earlier pass over the
@@ -207,7 +247,17 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
         step(True)
     env.fence()
     elapsed = time.perf_counter() - t0
+    scale_diag = None
     if env.use_dist:
+        # SCALE diagnostics (one glance at the first multi-GPU run): how many ranks RCCL saw, every rank's OWN time per step
+        # (imbalance between the shards -- SURVEY 8e's named risk -- shows here), its kernel time, and the gather
+        mine = torch.tensor([elapsed / steps * 1e3, float(np.mean(kernel_ms)), float(np.mean(gather_ms))], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(env.world)]
+        dist.all_gather(every, mine)
+        every = torch.stack(every).cpu().numpy()
+        scale_diag = {"ranks": int(dist.get_world_size()), "per_rank_ms": [float(v) for v in every[:, 0]],
+                      "per_rank_kernel_ms": [float(v) for v in every[:, 1]], "gather_ms": float(every[:, 2].max()),
+                      "gather_bytes_per_rank": int(dU.numel() * dU.element_size())}
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -280,6 +330,7 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
         "config": {"workload": f"{workload}: {desc}", "family": family, "batch_per_gpu": B, "N_hor": layout.N,
                    "Ndynobs": layout.Ndyn, "Nstcobs": layout.Nstc, "Nother": layout.Nother, "np": layout.np_,
                    "max_active_dynobs": int(cfg.max_active_dynobs), "latency_waves": int(cfg.latency_waves),
+                   "max_evaluations": int(getattr(cfg, "max_evaluations", 0)),
                    "dispatch": ("longest first by the evaluation counts of a previous pass over the same batch"
                                 if dispatch_hint else "index order"),
                    "lds_bytes_per_instance": int(kinfo["lds_bytes_" + dtype]),
@@ -296,8 +347,10 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
                      "valu_frac": achieved_tf / VALU_PEAK_TFLOPS, "flops_per_psi_eval": ff,
                      "psi_evals_per_solve": float(n_psi.mean()), "grad_evals_per_solve": float(n_grad.mean())},
         "polish": polished,
+        "scale": scale_diag,
         "harvest": harvest,
-        "solver": {"converged_frac": float(conv.mean()), "outer_iters_mean": float(iters[:, 0].mean()),
+        "solver": {"converged_frac": float(conv.mean()), "out_of_time_frac": float((status == 2).mean()),
+                   "outer_iters_mean": float(iters[:, 0].mean()),
                    "inner_iters_mean": float(iters[:, 1].mean()), "inner_iters_max": int(iters[:, 1].max()),
                    "converged": part(conv), "not_converged": part(~conv),
                    "converged_solves_per_s": float(conv.mean() * env.world * B * steps / elapsed)},
@@ -312,8 +365,9 @@ def main(argv=None, env_factory=Env):
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
-    ap.add_argument("--family", choices=("toward_robot", "oncoming", "passing", "closed_loop"), default="toward_robot",
-                    help="scenario family of the generator (SURVEY.md 8d prescribes toward_robot)")
+    ap.add_argument("--family", choices=("toward_robot", "oncoming", "passing", "closed_loop", "refscen"), default="toward_robot",
+                    help="scenario family of the generator (SURVEY.md 8d prescribes toward_robot); refscen / closed_loop: "
+                         "parameter vectors harvested from the closed loop on the reference's scenarios / the corridor family")
     ap.add_argument("--batch", type=int, default=None, help="override the per-GPU batch (default: BASELINE's)")
     ap.add_argument("--dtype", choices=("f32", "f64"), default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -362,6 +416,8 @@ def main(argv=None, env_factory=Env):
             "converged_solves_per_s": m["solver"]["converged_solves_per_s"],
             "solver": m["solver"],
         }
+        if m.get("scale"):      # launched under torch.distributed.run: ranks / per-rank times / gather time at the top level
+            detail.update(m["scale"])
         single = env.world == 1
         if single and not args.no_secondary:
             detail["secondary"] = secondary_workloads(env, args)
@@ -406,7 +462,7 @@ def secondary_key(row) -> str:
     w = row["workload"].split(":")[0]
     fam = "" if row["family"] == "toward_robot" else "_" + row["family"]
     b = f"_b{row['batch']}" if row.get("batch_override") else ""
-    return f"{w}{b}{fam}_{row['dtype']}" + ("_polish" if row.get("polish") else "") + \
+    return f"{w}{b}{fam}_{row['dtype']}" + ("_polish" if row.get("polish") else "") + ("_budget" if row.get("budget") else "") + \
         ("_hint" if row["dispatch"] != "index order" else "") + ("_nohint" if row.get("nohint") else "")
 
 
@@ -464,20 +520,33 @@ def compact_line(detail: dict) -> str:
     out["roofline"] = {k: _r(detail["roofline"][k], 6) for k in keep_roof if k in detail["roofline"]}
     out["converged_frac"] = _r(detail["converged_frac"])
     out["converged_solves_per_s"] = _r(detail["converged_solves_per_s"])
+    if "ranks" in detail:
+        out["ranks"] = detail["ranks"]
+        out["per_rank_ms"] = [_r(v, 6) for v in detail["per_rank_ms"]]
+        out["per_rank_kernel_ms"] = [_r(v, 6) for v in detail["per_rank_kernel_ms"]]
+        out["gather_ms"] = _r(detail["gather_ms"], 4)
+        out["gather_bytes_per_rank"] = detail["gather_bytes_per_rank"]
     if "cpu_baseline" in detail:
         cb = detail["cpu_baseline"]
         out["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind", "sample", "single_core_value", "value_trig_hoisted",
-                                                      "value_with_reference_time_cap", "converged_frac", "closed_loop_value", "open_probe")
+                                                      "value_with_reference_time_cap", "value_with_evaluation_budget", "evals_per_s_per_core", "converged_frac",
+                                                      "closed_loop_value", "open_probe")
                                if k in cb}
     if "secondary" in detail:
         out["secondary_solves_per_s"] = {secondary_key(r): _r(r["value"], 4) for r in detail["secondary"]}
         # the closed-loop distribution at the headline dimensions: which side of the north star's 1e5 it falls on, and how
         # much of it converges (the parity protocol on the same distribution: accuracy_summary.cfg2_closed_loop)
-        cl = [r for r in detail["secondary"] if r["family"] == "closed_loop" and not r.get("polish")]
-        if cl:
-            out["closed_loop"] = {"solves_per_s": _r(cl[0]["value"], 4), "converged_frac": _r(cl[0]["converged_frac"], 3),
-                                  "psi_evals_per_solve": _r(cl[0]["psi_evals_per_solve"], 4), "kernel_ms": _r(cl[0]["kernel_ms"], 4),
-                                  "capture_steps": list(CLOSED_LOOP_STEPS)}
+        for fam, key in (("refscen", "reference_scenarios"), ("closed_loop", "closed_loop")):
+            cl = [r for r in detail["secondary"] if r["family"] == fam and not r.get("polish") and not r.get("budget")]
+            bd = [r for r in detail["secondary"] if r["family"] == fam and r.get("budget")]
+            if cl:
+                out[key] = {"solves_per_s": _r(cl[0]["value"], 4), "converged_frac": _r(cl[0]["converged_frac"], 3),
+                            "psi_evals_per_solve": _r(cl[0]["psi_evals_per_solve"], 4), "kernel_ms": _r(cl[0]["kernel_ms"], 4),
+                            "capture_steps": list(HARVEST_STEPS[fam])}
+                if bd:      # the same batch under the reference's time cap as an evaluation budget
+                    out[key]["budget"] = {"max_evaluations": bd[0]["max_evaluations"], "solves_per_s": _r(bd[0]["value"], 4),
+                                          "out_of_time_frac": _r(bd[0]["out_of_time_frac"], 3),
+                                          "converged_frac": _r(bd[0]["converged_frac"], 3)}
     if "accuracy" in detail:
         out["accuracy_summary"] = accuracy_digest(detail["accuracy"])
     out["detail"] = "bench_detail.json"
@@ -498,11 +567,18 @@ def compact_line(detail: dict) -> str:
 
 def secondary_workloads(env: Env, args) -> list:
     """The other BASELINE configurations and the converging scenario family, one short timed run each."""
-    # (workload, family, dtype, steps, warmup, dispatch hint, batch override, polish, note)
-    runs = [("cfg2", "closed_loop", "f32", 2, 1, False, None, False,
-             "BASELINE configs[2] as written -- main_eva.py scenarios: parameter vectors harvested from the closed loop (row f3) "
-             "at 4 pedestrians x 10 hypotheses, a third each from time steps %s" % (CLOSED_LOOP_STEPS,)),
-            ("cfg2", "closed_loop", "f32", 2, 0, False, None, True, None),
+    # (workload, family, dtype, steps, warmup, dispatch hint, batch override, polish, note); note "budget" = the row runs with the
+    # reference's 0.1 s time cap as an evaluation budget (nmpc_config.max_evaluations) -- secondary rows only
+    runs = [("cfg2", "refscen", "f32", 2, 1, False, None, False,
+             "BASELINE configs[2] as written -- main_eva.py scenarios: the reference's scenario_0..2 on its 55-polygon warehouse "
+             "map (scenarios.make_reference_scenarios), 4 pedestrians x 10 hypotheses, parameter vectors harvested from the "
+             "closed loop (row f3), a third each from time steps %s" % (REFSCEN_STEPS,)),
+            ("cfg2", "refscen", "f32", 2, 0, False, None, False, "budget"),
+            ("cfg2", "refscen", "f32", 2, 0, False, None, True, None),
+            ("cfg2", "closed_loop", "f32", 2, 1, False, None, False,
+             "round 5's builder-designed corridor family, harvested the same way at time steps %s" % (CLOSED_LOOP_STEPS,)),
+            ("cfg2", "closed_loop", "f32", 2, 0, False, None, False, "budget"),
+            ("cfg2", "toward_robot", "f32", 2, 0, False, None, False, "budget"),
             ("cfg2", "passing", "f32", 2, 1, False, None, False, None),
             ("cfg1", "toward_robot", "f32", 5, 1, False, None, False, None),
             ("cfg1", "toward_robot", "f32", 5, 1, False, None, False, "nohint"),
@@ -522,17 +598,23 @@ def secondary_workloads(env: Env, args) -> list:
             ("cfg4", "toward_robot", "f32", 1, 0, True, None, False, None)]
     res = []
     for workload, family, dtype, steps, warmup, hint, batch, polish, note in runs:
-        if workload == args.workload and family == args.family and dtype == args.dtype and not hint and not batch and not polish:
+        nohint, budget = note == "nohint", note == "budget"
+        if workload == args.workload and family == args.family and dtype == args.dtype and not hint and not batch and not polish \
+                and not budget:
             continue
-        nohint = note == "nohint"
         if nohint:
             note = "configs[1] WITHOUT the capacity hint: all 15 obstacle rows of the shipped yaml provisioned (6-slot register table since round 5; the 14-slot one before)"
+        if budget:
+            note = ("the same batch with the reference's time cap (max_solver_time = 0.1 s of its CPU solver) as the deterministic "
+                    "evaluation budget nmpc_config.max_evaluations (solver.evaluation_budget): instances that use it up end "
+                    "NotConvergedOutOfTime with the point they reached, as the reference's do -- never the headline")
         r = run_workload(env, workload, family, dtype, steps, warmup, batch=batch, dispatch_hint=hint, polish=polish,
-                         capacity_hint=not nohint)
+                         capacity_hint=not nohint, budget=budget)
         r.pop("_host")
         r.pop("_gathered")
         res.append({"workload": r["config"]["workload"], "family": family, "dtype": dtype, "note": note,
-                    "batch_override": bool(batch), "nohint": nohint, "harvest": r["harvest"],
+                    "batch_override": bool(batch), "nohint": nohint, "budget": budget, "harvest": r["harvest"],
+                    "max_evaluations": r["config"]["max_evaluations"], "out_of_time_frac": r["solver"]["out_of_time_frac"],
                     "max_active_dynobs": r["config"]["max_active_dynobs"],
                     "polish": r["polish"],
                     "psi_evals_per_solve": r["roofline"]["psi_evals_per_solve"],
@@ -609,8 +691,13 @@ def cpu_baseline(layout, P_host):
     t_all = time.perf_counter() - t0
     n1 = min(sample, 16)
     t0 = time.perf_counter()
-    oracle.solve_batch(pr, oracle.Options(), Ps[:n1], nthreads=1)
+    _, r_one = oracle.solve_batch(pr, oracle.Options(), Ps[:n1], nthreads=1)
     t_one = time.perf_counter() - t0
+    # the constant behind max_solver_time -> max_evaluations (solver.evaluation_budget): evaluated points per second of this
+    # generated-code-equivalent CPU path on ONE core of this box, and the same in SURVEY 8(d)'s forward flops
+    from dyobav_mpcnwta_warehouse_amd.solver import CPU_FORWARD_FLOPS_PER_S, evaluation_budget, forward_flops
+    evals_per_s_core = float(r_one["n_points"].sum()) / t_one
+    ff = forward_flops(layout.N, layout.Nother, layout.Nstc, layout.Ndyn)
     # the same sample with the ellipses' cos / sin hoisted out of the evaluations (orc_options.hoist_trig: once per solve, same
     # bits). The default recomputes them on every evaluation, as the reference's CasADi-generated code does; a hand-tuned CPU
     # solver would not -- VERDICT r3 called the plain figure pessimistic, so both are reported.
@@ -622,6 +709,11 @@ def cpu_baseline(layout, P_host):
     t0 = time.perf_counter()
     _, rc = oracle.solve_batch(pr, oracle.Options(max_time_s=cap_s), Ps, nthreads=cores)
     t_cap = time.perf_counter() - t0
+    # ... and with that cap in its deterministic form (orc_options.max_evals = nmpc_config.max_evaluations of the `_budget` rows)
+    n_budget = evaluation_budget(REFERENCE_TIME_CAP_US, layout.N, layout.Nother, layout.Nstc, layout.Ndyn)
+    t0 = time.perf_counter()
+    _, rb = oracle.solve_batch(pr, oracle.Options(max_evals=n_budget), Ps, nthreads=cores)
+    t_bud = time.perf_counter() - t0
     # ... and on the closed-loop distribution of the same dimensions (configs[2] only: BASELINE's "main_eva.py scenarios",
     # scenarios.harvest_closed_loop -- the GPU row next to it is secondary_solves_per_s.cfg2_closed_loop_f32)
     closed = None
@@ -630,13 +722,15 @@ def cpu_baseline(layout, P_host):
             import dyobav_mpcnwta_warehouse_amd as nm
             cfg = nm.default_config_struct()
             cfg.Ndynobs, cfg.max_active_dynobs = layout.Ndyn, 40
-            Pc, _ = nm.scenarios.harvest_closed_loop(cfg, max(3 * sample // 2, 96), steps=CLOSED_LOOP_STEPS, seed=13, n_ped=4, n_hyp=10,
-                                                     dtype=np.float32)
+            # (round 6: the reference's own scenarios -- the GPU row next to it is secondary_solves_per_s.cfg2_refscen_f32)
+            Pc, _ = nm.scenarios.harvest_closed_loop(cfg, max(3 * sample // 2, 96), steps=REFSCEN_STEPS, seed=13, n_ped=4, n_hyp=10,
+                                                     dtype=np.float32, family="reference")
             Pc = np.ascontiguousarray(Pc[:sample], dtype=np.float64)
             t0 = time.perf_counter()
             _, rcl = oracle.solve_batch(pr, oracle.Options(), Pc, nthreads=cores)
             t_cl = time.perf_counter() - t0
-            closed = {"value": len(Pc) / t_cl, "sample": f"{len(Pc)} harvested instances, fp64, {t_cl:.1f} s wall",
+            closed = {"value": len(Pc) / t_cl, "scenarios": "reference (scenario_0..2 on the warehouse map)",
+                      "sample": f"{len(Pc)} harvested instances, fp64, {t_cl:.1f} s wall",
                       "converged_frac": float(np.mean(rcl["status"] == 0))}
         except Exception as exc:      # (the harvest needs the device; the baseline of the timed batch above must survive without)
             closed = {"error": repr(exc)[:200]}
@@ -649,6 +743,11 @@ def cpu_baseline(layout, P_host):
             "single_core_value": n1 / t_one, "single_core_sample": f"first {n1} instances, 1 thread",
             "value_trig_hoisted": sample / t_hoist,
             "value_with_reference_time_cap": sample / t_cap,
+            "evals_per_s_per_core": evals_per_s_core, "forward_flops_per_s_per_core": evals_per_s_core * ff,
+            "budget_constant_forward_flops_per_s": CPU_FORWARD_FLOPS_PER_S,
+            "value_with_evaluation_budget": sample / t_bud,
+            "evaluation_budget": {"max_evals": n_budget, "wall_s": t_bud, "out_of_time_frac": float(np.mean(rb["status"] == 2)),
+                                  "converged_frac": float(np.mean(rb["status"] == 0))},
             "reference_time_cap": {"max_solver_time_s": cap_s, "wall_s": t_cap,
                                    "out_of_time_frac": float(np.mean(rc["status"] == 2)),
                                    "converged_frac": float(np.mean(rc["status"] == 0))},
@@ -681,8 +780,9 @@ def accuracy_table(env: Env) -> dict:
                 lay = env.nm.scenarios.BENCH_CONFIGS["cfg2_b65536_n20_4x10"]["layout"]
                 cfg = env.nm.default_config_struct()
                 cfg.Ndynobs, cfg.max_active_dynobs = lay.Ndyn, 40
-                Pc, _ = env.nm.scenarios.harvest_closed_loop(cfg, 96, steps=CLOSED_LOOP_STEPS, seed=13, n_ped=4, n_hyp=10, dtype=np.float32)
-                rows.append(accuracy_protocol.run_case_on(env.nm, oracle, Pc[:32].astype(np.float64), lay, 40, "cfg2", "closed_loop",
+                Pc, _ = env.nm.scenarios.harvest_closed_loop(cfg, 96, steps=REFSCEN_STEPS, seed=13, n_ped=4, n_hyp=10, dtype=np.float32,
+                                                             family="reference")
+                rows.append(accuracy_protocol.run_case_on(env.nm, oracle, Pc[:32].astype(np.float64), lay, 40, "cfg2", "refscen",
                                                           nthreads=cores, tight=True, audit=True, audit_max=12, tight_audit=False,
                                                           n_tight=16))
     return {"protocol": "oracle64_vs_reassociated = the oracle's own noise floor (same fp64 algorithm, sums associated differently); "

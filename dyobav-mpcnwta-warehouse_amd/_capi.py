@@ -15,7 +15,7 @@ from . import build as _build
 
 EXIT_STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotFiniteComputation",
                      "CapacityExceeded", "NotAxisAligned")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class NmpcError(RuntimeError):
@@ -47,6 +47,7 @@ class NmpcConfigStruct(C.Structure):
         ("polish", C.c_int32), ("polish_max_outer_iterations", C.c_int32), ("polish_max_inner_iterations", C.c_int32),
         ("staged_evals", C.c_int32),
         ("polish_tolerance", C.c_double), ("polish_delta_tolerance", C.c_double),
+        ("max_evaluations", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -82,7 +82,6 @@ struct Layout {
     int lds_alpha, lds_poly, lds_seg, lds_seginv, lds_fl0, lds_fl, lds_iflag, lds_hist, lds_rho, lds_total;
     int lds_xch, lds_total_spec; // latency mode: exchange area + the other wavefronts' parking areas behind lds_total
     int lds_park;
-    int lds_lbc;          // workspace of the compact-form L-BFGS direction (qtab[N] Quads, R, Y'Y)
     int coop_lanes, lds_t0c; // cooperative kernels: lanes per plane of the exchange area; t = 0 rows of the compressed global table
     int lds_xch_coop, lds_total_coop; // cooperative mode: two shared parking areas, then the partial-sum exchange area
     int lds_left, lds_left_alpha;     // LDS table of the rows beyond the register-resident ones (cooperative register kernel)
@@ -182,8 +181,7 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false,
     L.lds_iflag = L.lds_fl + round4(c.Nother);         // int list: robots with a non-zero predicted position
     L.lds_hist = L.lds_iflag + round4(c.Ndynobs);  // int flags / compaction map (an int fits in a T)
     L.lds_rho = L.lds_hist + 4 * nmpc::kMem * nmpc::lbfgs_slot_stride(N); // L-BFGS ring: kMem slots x (N | 1) x (s_v, s_w, y_v, y_w)
-    L.lds_lbc = L.lds_rho + round4(2 * nmpc::kMem);    // rho[kMem], alpha[kMem]
-    L.lds_park = L.lds_lbc;                            // then the parking area(s) (16-B aligned)
+    L.lds_park = L.lds_rho + round4(2 * nmpc::kMem);   // rho[kMem], alpha[kMem]; then the parking area(s) (16-B aligned)
     const int park_one = nmpc::kParkQuads * 4 * 64;    // elements per wavefront
     L.lds_total = L.lds_park + park_one;
     // latency kernel: the exchange area of W wavefronts (nmpc_spec.h) in place of the parking area (its solver vectors stay
@@ -607,7 +605,6 @@ void fill_layout(nmpc::KParams<T>& k, const Layout& L)
     k.lds_total = L.lds_total;
     k.lds_xch = L.lds_xch;
     k.lds_park = L.lds_park;
-    k.lds_lbc = L.lds_lbc;
     k.coop_lanes = L.coop_lanes;
     k.lds_t0c = L.lds_t0c;
     k.lds_left = L.lds_left;
@@ -653,6 +650,7 @@ void fill_kparams(const nmpc_handle_s* h, nmpc::KParams<T>& k, const Layout* lay
     k.mem = c.lbfgs_memory;
     k.akkt_form = c.akkt_form;
     k.time_budget = c.max_solver_time_us > 0 ? (long long)(c.max_solver_time_us * 100.0 + 0.5) : 0; // 100 MHz ticks
+    k.max_evals = c.max_evaluations > 0 ? c.max_evaluations : 0;
 }
 
 // The same evaluation through the cooperative kernels' code path (W wavefronts share it; wavefront 0 writes): what
@@ -1196,6 +1194,7 @@ int polish_batch(nmpc_handle_s* h, const nmpc::KParams<T>& k, int B, bool y_user
         q.max_outer = c.polish_max_outer_iterations;
     }
     q.time_budget = 0;
+    q.max_evals = 0; // (the continuation of a converged instance is not budgeted)
     q.B = ns;
     q.P = static_cast<const double*>(h->pP.p);
     q.u0 = static_cast<const double*>(h->pU0.p);
@@ -1645,6 +1644,8 @@ int nmpc_default_config(nmpc_config* c)
     c->staged_evals = 0;
     c->polish_tolerance = 1e-6;
     c->polish_delta_tolerance = 1e-5;
+    c->max_evaluations = 0;
+    c->reserved0 = 0;
     return 0;
 }
 
@@ -1697,6 +1698,7 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "akkt_form = %d (0 = OpEn source form, 1 = documented form)", cfg->akkt_form);
     if (!(cfg->max_solver_time_us >= 0))
         return fail(NMPC_ERR_INVALID_ARGUMENT, "max_solver_time_us < 0");
+    if (cfg->max_evaluations < 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "max_evaluations = %d < 0", cfg->max_evaluations);
     if (cfg->staged_evals < -1) return fail(NMPC_ERR_INVALID_ARGUMENT, "staged_evals = %d < -1", cfg->staged_evals);
     if (cfg->axis_aligned < -1 || cfg->axis_aligned > 1)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "axis_aligned = %d (0 automatic, 1 promised, -1 never)", cfg->axis_aligned);

@@ -112,7 +112,16 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     int cont = 1;
     T cost_half = 0, normh = 0, fbe_cur = 0;
     int fbe_valid = 0;
-    int alg_psi = 0, alg_grad = 0, rounds = 0; // evaluations the sequential algorithm performs / exchange rounds
+    // Evaluations the sequential algorithm performs (gradient evaluations; exchange rounds). The psi evaluations are counted
+    // DOWN from the evaluation budget (nmpc_config.max_evaluations; none = INT_MAX): the budget test of every inner iteration
+    // is then a compare against zero and needs no scalar register of its own round the loop (a live budget next to the
+    // count cost the configs[1] kernel 1-3 %: profiles/r06_ab_evaluation_budget.jsonl). alg_psi = budget - evals_left.
+    auto evals_budget = [&]() {
+        const int me = cold_args<T>()->max_evals;
+        return me > 0 ? me : 0x7fffffff;
+    };
+    int evals_left = evals_budget();
+    int alg_grad = 0, rounds = 0;
     // max_solver_time: wavefront 0 publishes its elapsed real-time ticks with every exchange round, so that all
     // wavefronts of the workgroup take the same decision (see solve_instance)
     const long long time_budget = cold_args<T>()->time_budget;
@@ -174,7 +183,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         alm_iter = __builtin_amdgcn_readfirstlane((int)sc[4]);
         outer = __builtin_amdgcn_readfirstlane((int)sc[5]) + 1;
         inner_total = __builtin_amdgcn_readfirstlane((int)sc[6]);
-        alg_psi = __builtin_amdgcn_readfirstlane((int)sc[7]);
+        evals_left -= __builtin_amdgcn_readfirstlane((int)sc[7]);
         alg_grad = __builtin_amdgcn_readfirstlane((int)sc[8]);
         rounds = __builtin_amdgcn_readfirstlane((int)sc[9]);
         yv = tclamp(yv, T(-1e12), T(1e12));
@@ -245,6 +254,8 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     // are declared uniform where they are made (one ballot each), so that it lives in scalar registers all the way round
     // the loop -- see solve_instance (nmpc_device.h).
     auto anyb = [](bool cond) { return __builtin_amdgcn_ballot_w64(cond) != 0ull; };
+    // bit 0: wall-clock budget (max_solver_time_us), bit 1: evaluation budget (max_evaluations) -- one flag, so that the
+    // default path (neither) carries no further scalar register round the loop and reads nothing per iteration
     const int timed_ = __builtin_amdgcn_readfirstlane(time_budget > 0 ? 1 : 0);
     for (;;) {
         // wavefront index / budget flag as opaque per-round values: conditions on them are then evaluated where they
@@ -329,7 +340,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         // sequential line-search logic replayed on the exchanged results of wavefronts first..W-1
         auto process_candidates = [&](int first) -> bool {
             for (int w = first; w < W; ++w) {
-                alg_psi++;
+                evals_left--;
                 alg_grad++;
                 const T lhs = xr[w * XS + 2 * 64 + 1]; // the candidate's FBE, formed by the wavefront that evaluated it
                 if (anyb(lhs > rhs_ls) && nls < MAX_LS) {
@@ -357,7 +368,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         bool need_dir = false, spec = false; // run the L-BFGS update / direction block below
 
         if (phase == SP_INIT_A) {
-            alg_psi++;
+            evals_left--;
             alg_grad++;
             cost_value = r_psi;
             gv = r_gv;
@@ -375,7 +386,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             phase = SP_INIT_B;
             continue;
         } else if (phase == SP_INIT_B) {
-            alg_psi++;
+            evals_left--;
             alg_grad++;
             const T d1 = r_gv - gv, d2 = r_gw - gw;
             L = tsqrt(I.dot2(d1, d2, d1, d2)) / normh;
@@ -388,7 +399,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         } else if (phase == SP_LIP || phase == SP_SPEC0) {
             // SP_LIP: every wavefront evaluated psi(u_half) itself; SP_SPEC0: wavefront 0 did
             cost_half = phase == SP_SPEC0 ? xr[2 * 64] : r_psi;
-            alg_psi++;
+            evals_left--;
             const T ip = I.dot2(gv, gw, fv, fw);
             const T rhs = cost_value + LIP_EPS_UPD * tabs(cost_value) - ip +
                           (GAMMA_L * T(0.5) * inv_gamma) * (norm_fpr * norm_fpr);
@@ -424,7 +435,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 need_dir = true; // sequential path: L-BFGS update and direction now
             }
         } else if (phase == SP_NOLS) {
-            alg_psi++;
+            evals_left--;
             alg_grad++;
             fbe_valid = false;
             cost_value = r_psi;
@@ -441,7 +452,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 continue; // stay in SP_LSN
             }
         } else { // SP_OUTER
-            alg_psi++;
+            evals_left--;
             const auto* kc = cold_args<T>();
             const T f_u = r_psi;
             f2n_plus = tsqrt(r_f2);
@@ -480,13 +491,13 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 }
                 reset_cache();
                 if (outer >= kc->max_outer) finished = true;
-                else if (!cont_time) {
+                else if (!cont_time || evals_left <= 0) { // (nmpc_config.max_evaluations, see solve_instance)
                     finished = true;
                     out_of_time = true;
                 }
             }
             if (finished) {
-                if (!converged) status = (out_of_time || !cont_time) ? 2 : 1;
+                if (!converged) status = (out_of_time || status == 2) ? 2 : 1; // (status = how the last inner solve ended)
                 bool finite = tfinite(uv) && tfinite(uw) && tfinite(f_u);
                 if (__ballot(!finite) != 0ull) status = 3;
                 dismiss_workers();
@@ -516,7 +527,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                             o[1] = f2n_plus;
                             o[2] = dyn_plus;
                             o[3] = c;
-                            o[4] = T(alg_psi);
+                            o[4] = T(evals_budget() - evals_left);
                             o[5] = T(alg_grad);
                             o[6] = T(rounds); // exchange rounds (each = up to W evaluations in parallel)
                             o[7] = T(W);
@@ -547,7 +558,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                             sc[4] = T(alm_iter);
                             sc[5] = T(outer);
                             sc[6] = T(inner_total);
-                            sc[7] = T(alg_psi);
+                            sc[7] = T(evals_budget() - evals_left);
                             sc[8] = T(alg_grad);
                             sc[9] = T(rounds);
                             kc->status[ri] = -1;
@@ -575,6 +586,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                 num_iter++;
                 cont = num_iter < o_max_inner;
                 if (timed) cont_time = (long long)t_now <= time_budget;
+                if (evals_left <= 0) cont_time = 0; // (max_evaluations: the count of the sequential algorithm, independent of W)
                 step_head = true;
             }
         }

@@ -175,8 +175,16 @@ class BatchEvaluator:
         self.base_speed = lin_vel_max * scale
         self.lin_vel_max = lin_vel_max
         # global reference trajectories: TrajectoryTracker.get_ref_traj per scenario (host, once), padded
-        trajs = [np.array(TrajectoryTracker.get_ref_traj(self.ts, list(p), tuple(s), self.base_speed))
-                 for p, s in zip(robot_paths, robot_starts)]
+        # (the Monte-Carlo runs of one scenario share start and path: make_reference_scenarios has three distinct pairs
+        #  for any B -- one host call per distinct pair)
+        cache = {}
+
+        def ref_traj(p, s):
+            key = (tuple(map(tuple, p)), tuple(float(v) for v in s))
+            if key not in cache:
+                cache[key] = np.array(TrajectoryTracker.get_ref_traj(self.ts, list(p), tuple(s), self.base_speed))
+            return cache[key]
+        trajs = [ref_traj(p, s) for p, s in zip(robot_paths, robot_starts)]
         self.ref_len = torch.as_tensor([len(t) for t in trajs], device=self.dev)
         Lmax = max(len(t) for t in trajs)
         pad = np.stack([np.concatenate([t, np.repeat(t[-1:], Lmax - len(t), axis=0)]) for t in trajs])
@@ -195,6 +203,11 @@ class BatchEvaluator:
         self._evals = torch.zeros(B, dtype=self.tdt, device=self.dev)
         self.y = torch.zeros(B, 2 * self.N, dtype=self.tdt, device=self.dev)
         self.status = torch.empty(B, dtype=torch.int32, device=self.dev)
+        # count_status: the exit statuses of every time step's solves are counted on the device (status_counts: one [4]
+        # tensor per step -- Converged / NotConvergedIterations / NotConvergedOutOfTime / anything else) -- how often the
+        # evaluation budget (nmpc_config.max_evaluations) cuts a solve off, and how often the loop runs on a converged answer
+        self.count_status = False
+        self.status_counts: list = []
 
     # ---------------------------------------------------------------------------------------------------------
     def _predict_cv(self):
@@ -293,11 +306,11 @@ class BatchEvaluator:
         self.hcount = self.hcount + moving.long()
 
     # ---------------------------------------------------------------------------------------------------------
-    def _solve(self, hs, Pa, nA, Ua, u0, ya, y_is_input, info):
+    def _solve(self, hs, Pa, nA, Ua, u0, ya, y_is_input, info, status=None):
         """The MPC solves of one time step: parameters ``Pa[nA, np]`` -> controls ``Ua[nA, 2N]``, multipliers ``ya`` in / out
-        (device tensors; main_base.py:308-311 per scenario). One overridable call, so that a checker can drive the same
-        closed loop with another solver (tests/test_gpu_closed_loop.py puts the CPU oracle here)."""
-        hs.solve_raw(self.dt, Pa, nA, Ua, u0=u0, y=ya, y_is_input=y_is_input, info=info, sync=False)
+        (device tensors; main_base.py:308-311 per scenario), optionally the exit statuses. One overridable call, so that a
+        checker can drive the same closed loop with another solver (tests/test_gpu_closed_loop.py puts the CPU oracle here)."""
+        hs.solve_raw(self.dt, Pa, nA, Ua, status=status, u0=u0, y=ya, y_is_input=y_is_input, info=info, sync=False)
 
     def run(self, max_steps: int = 120, record: Optional[list] = None) -> EvaluationResult:
         """``record``: if a list, one dict per time step is appended with host copies of what the step saw and
@@ -393,7 +406,13 @@ class BatchEvaluator:
                 info = self._info[:nA]
             else:
                 info = None
-            self._solve(hs, Pa, nA, Ua, u0, ya, kt > 0, info)
+            if self.count_status:
+                st_buf = self.status[:nA]
+                st_buf.fill_(-2)      # (a solver put into _solve that does not report statuses leaves them uncounted)
+                self._solve(hs, Pa, nA, Ua, u0, ya, kt > 0, info, status=st_buf)
+                self.status_counts.append(torch.bincount(st_buf.clamp(min=-1, max=3) + 1, minlength=5)[1:])
+            else:
+                self._solve(hs, Pa, nA, Ua, u0, ya, kt > 0, info)
             if info is not None:
                 if full:
                     self._evals.copy_(info[:, 4])
@@ -480,7 +499,13 @@ class BatchEvaluator:
                 info = self._info[:nA]
             else:
                 info = None
-            self._solve(hs, Pa, nA, Ua, u0, ya, kt > 0, info)
+            if self.count_status:
+                st_buf = self.status[:nA]
+                st_buf.fill_(-2)      # (a solver put into _solve that does not report statuses leaves them uncounted)
+                self._solve(hs, Pa, nA, Ua, u0, ya, kt > 0, info, status=st_buf)
+                self.status_counts.append(torch.bincount(st_buf.clamp(min=-1, max=3) + 1, minlength=5)[1:])
+            else:
+                self._solve(hs, Pa, nA, Ua, u0, ya, kt > 0, info)
             if info is not None:
                 if full:
                     self._evals.copy_(info[:, 4])

@@ -266,13 +266,91 @@ def make_closed_loop_scenarios(B: int, seed: int = 13, n_ped: int = 4, n_boxes: 
                 map_polygons=np.array(boxes))
 
 
+_WAREHOUSE = None
+
+
+def warehouse_world() -> dict:
+    """The warehouse the reference evaluates in, as recorded from the reference (``data/warehouse_world.json``, written by
+    ``tests/golden/make_golden.py``: node graph of ``data/warehouse_sim_original/mygraph.json``, the 55 inflated static
+    rectangles its map pipeline extracts from ``mymap.pgm`` (main_base.py:123-127), and ``scenario_0..2`` of
+    main_base.py:36-58 -- all in world coordinates through the reference's own transform)."""
+    global _WAREHOUSE
+    if _WAREHOUSE is None:
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "warehouse_world.json")) as fh:
+            _WAREHOUSE = json.load(fh)
+    return _WAREHOUSE
+
+
+def make_reference_scenarios(B: int, seed: int = 13, n_ped: int = 4, n_waypoints: int = 4, scenario: int | None = None) -> dict:
+    """B Monte-Carlo runs of the REFERENCE's evaluation scenarios (main_eva.py:6-14 -> MainBase.run, main_base.py:448-464:
+    ``max_num_run`` repetitions of ``scenario(SCENARIO_NUM)`` with staggering pedestrians) on the reference's warehouse:
+
+    * run b is ``scenario_{b % 3}`` (or ``scenario`` for all): the robot's start state and node path exactly as
+      main_base.py:36-58 / ``_prepare_agents`` (:129-150) give them, the 55 static rectangles of the warehouse map;
+    * pedestrian 0 is the scenario's own pedestrian (its start point and node path);
+    * pedestrians 1 .. n_ped - 1 -- BASELINE configs[2] has four -- walk other node paths of the same graph: a seeded
+      non-backtracking walk of ``n_waypoints`` nodes that starts at most two edges away from a node of the robot's path
+      (and at least 3 m from the robot's start), from a point within 0.5 m of its first node;
+    * every pedestrian moves at HUMAN_VMAX with the stagger of basic_agent.py:64-82 (``human_stagger`` =
+      HUMAN_STAGGER = 0.5 is the evaluator's argument; seeded per run).
+
+    Deterministic in (B, seed, n_ped, n_waypoints, scenario). Returns the keyword arguments of ``BatchEvaluator`` plus
+    ``scenario_index`` [B]."""
+    w = warehouse_world()
+    nodes = {int(k): np.array(v, dtype=float) for k, v in w["nodes_world"].items()}
+    adj: dict = {k: [] for k in nodes}
+    for a, b in w["graph_edges"]:
+        adj[a].append(b)
+        adj[b].append(a)
+    rng = np.random.default_rng(seed)
+    W = n_waypoints
+    near = {}          # scenario -> candidate first nodes of the extra pedestrians
+    for k, sc in w["scenarios"].items():
+        reach = set(sc["robot_path"])
+        for _ in range(2):
+            reach |= {n for r in list(reach) for n in adj[r]}
+        st = np.array(sc["robot_start_world"][:2])
+        near[int(k)] = sorted(n for n in reach if np.linalg.norm(nodes[n] - st) >= 3.0)
+    sidx = np.full(B, scenario, dtype=np.int64) if scenario is not None else np.arange(B) % 3
+    starts = np.empty((B, 3))
+    paths = []
+    hstart = np.empty((B, n_ped, 2))
+    hpath = np.empty((B, n_ped, W, 2))
+    for b in range(B):
+        sc = w["scenarios"][str(int(sidx[b]))]
+        starts[b] = sc["robot_start_world"]
+        paths.append([tuple(p) for p in sc["robot_path_world"]])
+        own = [np.array(p) for p in sc["human_paths_world"][0]]
+        hstart[b, 0] = sc["human_starts_world"][0]
+        hpath[b, 0] = np.stack((own + [own[-1]] * W)[:W])
+        for h in range(1, n_ped):
+            cand = near[int(sidx[b])]
+            walk = [cand[int(rng.integers(len(cand)))]]
+            while len(walk) < W + 1:
+                nxt = [n for n in adj[walk[-1]] if len(walk) < 2 or n != walk[-2]] or adj[walk[-1]]
+                walk.append(nxt[int(rng.integers(len(nxt)))])
+            hstart[b, h] = nodes[walk[0]] + rng.uniform(-0.5, 0.5, 2)
+            hpath[b, h] = np.stack([nodes[n] for n in walk[1:]])
+    return dict(robot_starts=starts, robot_paths=paths, human_starts=hstart, human_paths=hpath,
+                map_polygons=np.array(w["map_polygons_world"], dtype=float), scenario_index=sidx)
+
+
+HUMAN_STAGGER = 0.5     # main_base.py:77
+
+
 def harvest_closed_loop(config, B: int, steps=(1, 8, 20), seed: int = 13, n_ped: int = 4, n_hyp: int = 10,
-                        dtype=np.float32, human_stagger: float = 0.2, return_device: bool = False):
+                        dtype=np.float32, human_stagger: float | None = None, return_device: bool = False,
+                        family: str = "corridor"):
     """Parameter vectors ``P[B, np]`` as the closed loop produces them: ``make_closed_loop_scenarios(B, seed, n_ped)``
     advanced by ``evaluate.BatchEvaluator`` (row f3, pinned to the reference) with ``n_hyp`` hypotheses per pedestrian
     fanned around the constant-velocity prediction (``config.Ndynobs`` >= n_ped * n_hyp), and the assembled
-    parameter vector of scenario b captured at time step ``steps[b % len(steps)]`` (early / mid-run / near the goal) --
-    or at the last earlier capture step it was still running. Needs the GPU (the closed loop solves on the device).
+    parameter vector of scenario b captured at time step ``steps[b % len(steps)]`` (reference family: ``steps[(b // 3) %
+    len(steps)]``: every scenario at every step) --
+    or at the last earlier capture step it was still running. ``family``: ``"reference"`` = ``make_reference_scenarios``
+    (scenario_0..2 on the warehouse map, HUMAN_STAGGER 0.5), ``"corridor"`` = ``make_closed_loop_scenarios`` (round 5).
+    Needs the GPU (the closed loop solves on the device).
     Returns ``(P, step_of_row)``: numpy arrays, or torch device tensors with ``return_device``."""
     import copy
 
@@ -280,7 +358,15 @@ def harvest_closed_loop(config, B: int, steps=(1, 8, 20), seed: int = 13, n_ped:
 
     from .evaluate import BatchEvaluator
     steps = tuple(sorted(int(s) for s in steps))
-    sc = make_closed_loop_scenarios(B, seed=seed, n_ped=n_ped)
+    if family == "reference":      # the reference's own scenarios on its warehouse map, HUMAN_STAGGER as main_base.py:77
+        sc = make_reference_scenarios(B, seed=seed, n_ped=n_ped)
+        sc.pop("scenario_index")
+        human_stagger = HUMAN_STAGGER if human_stagger is None else human_stagger
+    elif family == "corridor":     # the builder-designed corridor family of round 5
+        sc = make_closed_loop_scenarios(B, seed=seed, n_ped=n_ped)
+        human_stagger = 0.2 if human_stagger is None else human_stagger
+    else:
+        raise ValueError(f"family = {family!r} (reference or corridor)")
     cfg = copy.copy(config)
     cfg.max_active_dynobs = n_ped * n_hyp
     ev = BatchEvaluator(cfg, dtype=dtype, human_stagger=human_stagger, seed=seed, n_hyp=n_hyp, **sc)
@@ -288,13 +374,20 @@ def harvest_closed_loop(config, B: int, steps=(1, 8, 20), seed: int = 13, n_ped:
     out = torch.zeros(B, ev.h.np_, dtype=ev.tdt, device=ev.dev)
     step_of = torch.full((B,), -1, dtype=torch.int32, device=ev.dev)
     ns = len(steps)
+    # capture slot of scenario b: b % ns -- for the reference family (b // 3) % ns, so that every one of its three
+    # scenarios (b % 3) is captured at every step
+    slot = torch.arange(B, device=ev.dev)
+    slot = (slot // 3) % ns if family == "reference" else slot % ns
 
     def grab(kt, idx, Pa):
         if kt not in steps:
             return
         i = steps.index(kt)
         rows = idx if idx is not None else torch.arange(B, device=ev.dev)
-        take = (rows % ns == i) | (step_of[rows] < 0)
+        # slot i is the capture step of the scenarios with slot[b] == i; a scenario whose own step comes later takes every
+        # earlier capture step too and is overwritten until its own -- so one that stops running in between keeps the LAST
+        # capture step it was still running at (`| step_of < 0` kept the first)
+        take = slot[rows] >= i
         rsel = rows[take]
         out[rsel] = Pa[:rows.numel()][take]
         step_of[rsel] = kt
@@ -302,6 +395,10 @@ def harvest_closed_loop(config, B: int, steps=(1, 8, 20), seed: int = 13, n_ped:
     ev.on_params = grab
     ev.run(max_steps=steps[-1] + 1)
     ev.close()
+    if steps[0] == 0 or bool((step_of >= 0).all()):
+        pass
+    else:       # (a scenario that is over before the first capture step would leave an all-zero parameter row behind)
+        raise RuntimeError(f"{int((step_of < 0).sum())} scenarios ended before the first capture step {steps[0]}")
     if return_device:
         return out, step_of
     return out.cpu().numpy(), step_of.cpu().numpy()

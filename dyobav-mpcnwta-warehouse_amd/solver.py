@@ -25,17 +25,59 @@ _ROBOT_FIELDS = ("ts", "lin_vel_min", "lin_vel_max", "ang_vel_max", "lin_acc_min
                  "vehicle_width", "vehicle_margin", "social_margin")
 
 
-def make_config(mpc_config=None, robot_spec=None, device_id: int = 0, **overrides) -> NmpcConfigStruct:
+# ---- yaml `max_solver_time` as an evaluation budget ------------------------------------------------------------------
+# OpEn stops a solve after `max_solver_time` micro-seconds of ITS OWN wall clock (`with_max_duration_micros`,
+# mpc_builder.py:189; 0.1 s in mpc_fast.yaml, 0.5 s in mpc_default.yaml) and the tracker goes on with the truncated
+# answer (trajectory_tracker.py:318-335 only prints). What that cap means for the RESULT is "as many psi / grad-psi
+# evaluations as one host core of the reference's machine gets through in that time" -- the GPU's own clock has nothing to
+# do with it (one problem takes 1-20 ms here; a batch of 65 536 takes a second) and a wall-clock cap makes results depend
+# on the batch, the clock and the co-residents. `nmpc_config.max_evaluations` is the same cap as a count; this is the
+# mapping:
+#     max_evaluations = max_solver_time [s] x CPU_FORWARD_FLOPS_PER_S / forward_flops(N, Nother, Nstc, Ndyn)
+# with forward_flops = SURVEY.md 8(d)'s F_fwd (the work of one evaluation grows with the dimensions the yaml sets) and
+# CPU_FORWARD_FLOPS_PER_S the measured rate of the generated-code-equivalent CPU path -- the fp64 oracle with cos / sin of
+# every ellipse on every evaluation and cost / gradient as separate calls -- on ONE core, in evaluated points x F_fwd per
+# second: tools/measure_cpu_eval_rate.py (profiles/r06_cpu_eval_rate.json: 1.44-2.04e9, median 1.64e9, over two dimension
+# sets x two scenario families on this round's build container -- the flop scaling between 15 and 40 obstacle rows holds to
+# ~10 %; the GPU box's host in round 5: 3.5 solves/s per core x 6 665 evaluations = 1.48e9; bench.py re-measures it on
+# every run, `cpu_baseline.evals_per_s_per_core`). Shipped yaml (N = 20, 15 obstacle rows): 0.1 s -> 4 947 evaluations,
+# 0.5 s -> 24 737; configs[2] (40 rows): 0.1 s -> 2 526 -- against ~6 650 evaluations for an instance that runs to its
+# iteration caps and 10-300 for one that converges.
+CPU_FORWARD_FLOPS_PER_S = 1.6e9
+
+
+def forward_flops(N: int, Nother: int, Nstc: int, Ndyn: int) -> int:
+    """Algorithmic flops of one forward evaluation of psi, SURVEY.md 8(d):
+    N (33 + 8 (2 Nother - 1) + 28 Nstc + 62 Ndyn) + 10 N (N + 1) + 12 N."""
+    return N * (33 + 8 * (2 * Nother - 1) + 28 * Nstc + 62 * Ndyn) + 10 * N * (N + 1) + 12 * N
+
+
+def evaluation_budget(max_solver_time_us: float, N: int, Nother: int, Nstc: int, Ndyn: int,
+                      cpu_forward_flops_per_s: float = CPU_FORWARD_FLOPS_PER_S) -> int:
+    """`max_solver_time` (micro-seconds of the reference's CPU solver) -> `nmpc_config.max_evaluations` (see above)."""
+    if not max_solver_time_us or max_solver_time_us <= 0:
+        return 0
+    return max(1, int(round(max_solver_time_us * 1e-6 * cpu_forward_flops_per_s / forward_flops(N, Nother, Nstc, Ndyn))))
+
+
+def make_config(mpc_config=None, robot_spec=None, device_id: int = 0, time_cap: str = "evaluations",
+                **overrides) -> NmpcConfigStruct:
     """``nmpc_config`` from the reference-style configuration objects (``configs.MpcConfiguration`` /
     ``configs.CircularRobotSpecification``); unspecified values are the OpEn defaults the reference builds with
     (``solver_build/mpc_builder.py:187-195``).
 
-    ``max_solver_time`` (micro-seconds; ``with_max_duration_micros``, ``mpc_builder.py:189``) becomes
-    ``nmpc_config.max_solver_time_us``: every instance checks the GPU's real-time counter once per inner iteration and
-    before every outer iteration, exactly where OpEn checks its clock, and reports ``NotConvergedOutOfTime`` when the
-    budget is used up (``bad_exit_codes`` of the yaml files, ``trajectory_tracker.py:334-335``). For the shipped
-    0.1 s a solve of one problem (~3 ms) never gets near it.
+    ``max_solver_time`` (micro-seconds; ``with_max_duration_micros``, ``mpc_builder.py:189``), ``time_cap``:
+
+    * ``"evaluations"`` (default) -- ``nmpc_config.max_evaluations = evaluation_budget(max_solver_time, dims)``: the
+      deterministic, batch-safe form. An instance that uses its budget up stops where OpEn stops when its clock runs out
+      (after the inner iteration in progress; no further outer iteration) and reports ``NotConvergedOutOfTime``
+      (``bad_exit_codes`` of the yaml files, ``trajectory_tracker.py:334-335``) with the point it has reached.
+    * ``"wall_clock"`` -- ``nmpc_config.max_solver_time_us``: the GPU's 100 MHz real-time counter per instance. Only
+      meaningful for B = 1 (results depend on the clock and on what else runs); kept for callers that want a latency bound.
+    * ``"none"`` -- iteration caps only (what the batch API's ``default_config_struct`` gives).
     """
+    if time_cap not in ("evaluations", "wall_clock", "none"):
+        raise ValueError(f"time_cap = {time_cap!r} (evaluations, wall_clock or none)")
     cfg = default_config_struct()
     cfg.device_id = device_id
     if mpc_config is not None:
@@ -45,8 +87,11 @@ def make_config(mpc_config=None, robot_spec=None, device_id: int = 0, **override
                 int(mpc_config.nstcobs) != 12 or int(mpc_config.ndynobs) != 6:
             raise ValueError("the kernels implement ns=3, nu=2, nq=10, nstcobs=12, ndynobs=6 (the shipped yaml values)")
         cfg.ts = float(mpc_config.ts)
-        if getattr(mpc_config, "max_solver_time", None):
-            cfg.max_solver_time_us = float(mpc_config.max_solver_time)
+        t_us = float(getattr(mpc_config, "max_solver_time", None) or 0.0)
+        if t_us > 0 and time_cap == "wall_clock":
+            cfg.max_solver_time_us = t_us
+        elif t_us > 0 and time_cap == "evaluations":
+            cfg.max_evaluations = evaluation_budget(t_us, cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs)
     if robot_spec is not None:
         for k in _ROBOT_FIELDS:
             setattr(cfg, k, float(getattr(robot_spec, k)))

@@ -36,19 +36,21 @@ class _Options(C.Structure):
                 ("inner_tol_update", C.c_double), ("sufficient_decrease", C.c_double),
                 ("lip_delta", C.c_double), ("lip_eps", C.c_double),
                 ("cbfgs_alpha", C.c_double), ("cbfgs_eps", C.c_double), ("sy_eps", C.c_double),
-                ("akkt_form", C.c_int32), ("hoist_trig", C.c_int32), ("max_time_s", C.c_double)]
+                ("akkt_form", C.c_int32), ("hoist_trig", C.c_int32), ("max_time_s", C.c_double),
+                ("max_evals", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class _Result(C.Structure):
     _fields_ = [("cost", C.c_double), ("status", C.c_int32), ("outer_iters", C.c_int32),
                 ("inner_iters", C.c_int32), ("n_cost_evals", C.c_int32), ("n_grad_evals", C.c_int32),
                 ("last_fpr", C.c_double), ("delta_y_norm", C.c_double), ("f2_norm", C.c_double),
-                ("penalty", C.c_double)]
+                ("penalty", C.c_double), ("n_points", C.c_int32), ("reserved_", C.c_int32)]
 
 
 RESULT_DTYPE = np.dtype([("cost", "f8"), ("status", "i4"), ("outer_iters", "i4"), ("inner_iters", "i4"),
                          ("n_cost_evals", "i4"), ("n_grad_evals", "i4"), ("last_fpr", "f8"),
-                         ("delta_y_norm", "f8"), ("f2_norm", "f8"), ("penalty", "f8")], align=True)
+                         ("delta_y_norm", "f8"), ("f2_norm", "f8"), ("penalty", "f8"), ("n_points", "i4"),
+                         ("reserved_", "i4")], align=True)
 assert RESULT_DTYPE.itemsize == C.sizeof(_Result)
 
 
@@ -130,13 +132,15 @@ class Options:
     akkt_form: int = 0   # 0 = OpEn source form of the AKKT residual, 1 = documented form (see nmpc_oracle.h)
     max_time_s: float = 0.0   # wall-clock budget of one solve (the reference's max_solver_time: 0.1 s); 0 = none
     hoist_trig: int = 0       # 1: cos / sin of the ellipse angles once per solve instead of per evaluation (same bits)
+    max_evals: int = 0        # evaluation budget of one solve (points, = the kernels' info[4]; nmpc_config.max_evaluations); 0 = none
     extra: dict = field(default_factory=dict)
 
     def c(self) -> _Options:
         return _Options(self.tolerance, self.initial_tolerance, self.delta_tolerance, self.max_outer,
                         self.max_inner, self.lbfgs_mem, self.initial_penalty, self.penalty_update,
                         self.inner_tol_update, self.sufficient_decrease, self.lip_delta, self.lip_eps,
-                        self.cbfgs_alpha, self.cbfgs_eps, self.sy_eps, self.akkt_form, self.hoist_trig, self.max_time_s)
+                        self.cbfgs_alpha, self.cbfgs_eps, self.sy_eps, self.akkt_form, self.hoist_trig, self.max_time_s,
+                        self.max_evals, 0)
 
 
 TRACE_HEAD = 16   # ORC_TRACE_HEAD

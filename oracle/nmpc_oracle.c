@@ -45,6 +45,8 @@ void orc_default_options(orc_options *o)
     o->akkt_form = 0;
     o->hoist_trig = 0;
     o->max_time_s = 0.0;
+    o->max_evals = 0;
+    o->reserved_ = 0;
 }
 
 /* ---------------- double ---------------- */

@@ -70,6 +70,14 @@ typedef struct {
     double max_time_s;           /* wall-clock budget of one solve (the reference: with_max_duration_micros = 0.1 s,
                                     mpc_builder.py:189): the inner loop stops once it is used up and no further outer
                                     iteration is started (status 2); 0 = none (default: iteration caps only) */
+    int32_t max_evals;           /* the same cap as a COUNT (deterministic, what nmpc_config.max_evaluations does on the
+                                    device): budget of "points" -- distinct arguments at which psi (and possibly grad psi)
+                                    is evaluated: every gradient call, every psi(u_half) of the Lipschitz test, the
+                                    F1 / F2 evaluation behind each inner solve (orc_result.n_points; the kernels'
+                                    info[4]). Tested where OpEn reads its clock: after every inner iteration the loop
+                                    goes on only while n_points < max_evals, and no further outer iteration is started
+                                    once n_points >= max_evals (status 2). 0 = none */
+    int32_t reserved_;
 } orc_options;
 
 typedef struct {
@@ -83,6 +91,8 @@ typedef struct {
     double delta_y_norm;
     double f2_norm;
     double penalty;
+    int32_t n_points;            /* points evaluated (see orc_options.max_evals) = what the HIP kernels report as info[4] */
+    int32_t reserved_;
 } orc_result;
 
 #define ORC_MAX_MEM 32

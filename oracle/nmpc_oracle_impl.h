@@ -388,6 +388,7 @@ typedef struct {
     REAL c;
     const REAL *y;
     int n_cost, n_grad;
+    int n_points; /* distinct arguments evaluated so far (orc_options.max_evals) */
     /* optional iteration trace (orc_solve_trace_*): one record of ORC_TRACE_HEAD + n doubles per completed inner
      * iteration -- see nmpc_oracle.h */
     double *trace;
@@ -423,6 +424,7 @@ static void SUF(gradf)(SUF(ctx) * cx, const REAL *u, REAL *g)
     REAL v;
     SUF(core)(cx->pr, u, cx->c, cx->y, cx->p, 0, 0, 0, &v, g);
     cx->n_grad++;
+    cx->n_points++; /* (every gradient is taken at a new point; the cost call that goes with it is the same point) */
 }
 static REAL SUF(dot)(const REAL *a, const REAL *b, int n)
 {
@@ -640,7 +642,8 @@ static int SUF(panoc_step)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u)
     /* update_lipschitz_constant */
     {
         REAL cost_half = SUF(cost)(cx, pc->u_half);
-        pc->cost_value = SUF(cost)(cx, u);
+        cx->n_points++;
+        pc->cost_value = SUF(cost)(cx, u); /* (same point as the last gradient: not a new one) */
         int it = 0;
         for (;;) {
             REAL ip = SUF(dot)(pc->grad, pc->gfpr, n);
@@ -654,6 +657,7 @@ static int SUF(panoc_step)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u)
             SUF(gradient_step)(pc, u, n);
             SUF(half_step)(cx, pc);
             cost_half = SUF(cost)(cx, pc->u_half);
+            cx->n_points++;
             for (int i = 0; i < n; ++i) pc->gfpr[i] = u[i] - pc->u_half[i];
             pc->norm_gfpr = SUF(norm2)(pc->gfpr, n);
             ++it;
@@ -753,6 +757,7 @@ static int SUF(panoc_solve)(SUF(ctx) * cx, SUF(pcache) * pc, REAL *u, int max_it
         num_iter++;
         cont_iters = num_iter < max_iter;
         if (t_end > 0) cont_time = orc_now() <= t_end;   /* (remaining time checked once per iteration, like OpEn) */
+        if (cx->op->max_evals > 0 && cx->n_points >= cx->op->max_evals) cont_time = 0; /* the same test on the count */
         flag = SUF(panoc_step)(cx, pc, u);
     }
     for (int i = 0; i < cx->n; ++i) u[i] = pc->u_half[i];
@@ -774,7 +779,7 @@ static int SUF(orc_solve_impl)(const orc_problem *pr, const orc_options *op, con
     pc->lb.gamma = 1;
     pc->tol = (REAL)op->tolerance;
     pc->akkt_tol = (REAL)op->initial_tolerance;
-    SUF(ctx) cx = {pr, op, p, n, (REAL)op->initial_penalty, y, 0, 0, trace, max_rec, 0, 0, 0, 0, -1, 0, 0.0, 0.0, 0.0, 0};
+    SUF(ctx) cx = {pr, op, p, n, (REAL)op->initial_penalty, y, 0, 0, 0, trace, max_rec, 0, 0, 0, 0, -1, 0, 0.0, 0.0, 0.0, 0};
 
     REAL y_plus[ORC_MAXNV], F1[ORC_MAXNV], F2[ORC_MAXDYN];
     REAL dyn = 0, dyn_plus = 0, f2n = 0, f2n_plus = 0, last_fpr = 0;
@@ -799,7 +804,8 @@ static int SUF(orc_solve_impl)(const orc_problem *pr, const orc_options *op, con
         }
     }
     for (int it = 0; it < op->max_outer; ++it) {
-        if (t_end > 0 && it > 0 && orc_now() > t_end) { /* no time left for another outer iteration */
+        if (it > 0 && ((t_end > 0 && orc_now() > t_end) || (op->max_evals > 0 && cx.n_points >= op->max_evals))) {
+            /* no time (no evaluation budget) left for another outer iteration */
             out_of_time = 1;
             break;
         }
@@ -815,6 +821,7 @@ static int SUF(orc_solve_impl)(const orc_problem *pr, const orc_options *op, con
                                                    outer iteration: the exit status is OutOfTime, not Iterations) */
         /* update_lagrange_multipliers: y+ = y + c [F1(u) - Proj_C(F1(u) + y/c)] ; F2 norm */
         SUF(core)(pr, u, 0, 0, p, 0, F1, F2, 0, 0);
+        cx.n_points++;
         for (int i = 0; i < n1; ++i) {
             REAL lo = i < N ? (REAL)pr->lin_acc_min : (REAL)(-pr->ang_acc_max);
             REAL hi = i < N ? (REAL)pr->lin_acc_max : (REAL)pr->ang_acc_max;
@@ -886,6 +893,8 @@ static int SUF(orc_solve_impl)(const orc_problem *pr, const orc_options *op, con
         res->delta_y_norm = (double)dyn_plus;
         res->f2_norm = (double)f2n_plus;
         res->penalty = (double)cx.c;
+        res->n_points = cx.n_points;
+        res->reserved_ = 0;
     }
     if (n_rec) *n_rec = cx.n_rec;
     SUF(tl_trig) = 0;

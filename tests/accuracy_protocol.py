@@ -53,7 +53,7 @@ LIP_STEP_TIGHT = 1e-7
 # -- evaluated by the OTHER implementation -- is below this. Genuine stationary points of these problems come out at 1e-5..2e-3
 # (the exit test bounds ||gamma fpr||, i.e. this residual only to ~tol / gamma); end points "converged" after the penalty has
 # escalated to 1e7..1e10 come out at 0.5..2: there gamma ~ 1 / c makes ||gamma fpr|| < tol true at non-stationary points.
-RHO_KKT = 1e-2
+RHO_KKT = 5e-3     # (1e-2 was 5x above the largest genuine stationary residual measured; 2.5x now, 100x below the escalated ones)
 
 # workload name -> (scenario key of scenarios.BENCH_CONFIGS, instances per family)
 WORKLOADS = {"cfg1": ("cfg1_b1024_n20_2x5", 48), "cfg2": ("cfg2_b65536_n20_4x10", 32), "cfg4": ("cfg4_b8192_n40_8x20", 8)}
@@ -240,11 +240,15 @@ def kkt_classification(oracle, pr, P, idx, end_a, end_b, eval_hip=None) -> dict:
                 rec[name]["psi_rel_diff_hip_vs_oracle"] = float(abs(hip[name]["psi"][n] - v) / max(1.0, abs(v)))
         du = float(np.abs(end_a[0][n] - end_b[0][n]).max())
         rho_max = max(max(rec[s].get("rho_hip", 0.0), rec[s]["rho_oracle"]) for s in ("a", "b"))
+        # an end point counts as NOT stationary only if BOTH evaluators say so (`rho_max` alone took the
+        # larger of the two, so that one evaluator's error could excuse a pair); "both end points stationary" keeps the
+        # stricter reading: the larger residual of either evaluator at either end
+        rho_nonstat = max(min(rec[s].get("rho_hip", rec[s]["rho_oracle"]), rec[s]["rho_oracle"]) for s in ("a", "b"))
         df = abs(rec["a"]["f"] - rec["b"]["f"])
-        rec.update({"abs_du": du, "rho_max": rho_max, "abs_df": df})
+        rec.update({"abs_du": du, "rho_max": rho_max, "rho_nonstationary_by_both": rho_nonstat, "abs_df": df})
         if du <= 1e-4:
             rec["kind"] = "agree"
-        elif rho_max > RHO_KKT:
+        elif rho_nonstat > RHO_KKT:
             rec["kind"] = "not_kkt"
         elif df > 1e-9 * max(1.0, abs(rec["a"]["f"])):
             rec["kind"] = "second_kkt_point"

@@ -367,6 +367,19 @@ def main(out_dir=None):
         json.dump(ec, fh)
     print("evaluate_cases.json:", {k: (len(v) if hasattr(v, "__len__") else v) for k, v in ec.items()})
 
+    # The warehouse the reference evaluates in, as DATA for scenarios.make_reference_scenarios (row f3): node graph, static
+    # map and the three scenario definitions in world coordinates -- a subset of evaluate_cases.json, also shipped inside
+    # the package (dyobav-mpcnwta-warehouse_amd/data/warehouse_world.json; tests/test_host_mirror.py keeps the two identical).
+    ww = {"source": "recorded by tests/golden/make_golden.py from the reference's main_base.py:36-77, "
+                    "data/warehouse_sim_original/{mygraph.json,mymap.pgm} and config/global_setting_warehouse.yaml through the "
+                    "reference's own ScaleOffsetReverseTransform / MapInterface (world coordinates, metres)",
+          "nodes_world": ec["scenario_0"]["nodes_world"], "graph_edges": ec["graph_edges"], "scenarios": ec["scenarios"],
+          "map_polygons_world": ec["scenario_0_map"]["polygons_world"], "map_boundary_world": ec["scenario_0_map"]["boundary_world"],
+          "constants": ec["main_base_constants"]}
+    with open(os.path.join(OUT, "warehouse_world.json"), "w") as fh:
+        json.dump(ww, fh)
+    print("warehouse_world.json:", len(ww["nodes_world"]), "nodes,", len(ww["graph_edges"]), "edges,", len(ww["map_polygons_world"]), "polygons")
+
 
 # ---------------------------------------------------------------------------------------------------------
 def assemble_fixture(K=6, seed=77):
@@ -631,6 +644,41 @@ def evaluate_fixture(seed=2024):
         "robot_start_world": [float(x) for x in ct(np.array(robot_start[:2]))] + [robot_start[2]],
         "transform": {"scale": g["scale2real"], "offset": g["corner_coords"], "sim_height": g["sim_height"],
                       "image_axis": g["image_axis"]}}
+    # Round 6: all three evaluation scenarios of the reference (main_base.py:36-58; main_eva.py:6-14 runs MainBase on
+    # SCENARIO_NUM, main_base.py:79-80), taken from the reference's OWN functions: main_base.py cannot be imported whole
+    # here (matplotlib backends, shapely, the predictor package), so the three function definitions are lifted out of its
+    # syntax tree and executed as they stand; start points and node paths go through the reference's transform exactly as
+    # MainBase._prepare_agents does (main_base.py:136-141). Plus the edges of the node graph the paths live on
+    # (data/warehouse_sim_original/mygraph.json), for pedestrians on other node paths of the same warehouse.
+    import ast
+    import math
+    tree = ast.parse(open(os.path.join(REF, "src", "main_base.py")).read())
+    ns = {"np": np, "math": math}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("scenario_0", "scenario_1", "scenario_2"):
+            exec(compile(ast.Module(body=[node], type_ignores=[]), "main_base.py", "exec"), ns)
+    scen = {}
+    for k in (0, 1, 2):
+        human_starts, human_paths, robot_start, robot_path = ns["scenario_%d" % k]()
+        scen[str(k)] = {
+            "human_starts_sim": [[float(v) for v in h] for h in human_starts], "human_paths": [[int(n) for n in p] for p in human_paths],
+            "robot_start_sim": [float(v) for v in robot_start], "robot_path": [int(n) for n in robot_path],
+            "human_starts_world": [[float(x) for x in ct(np.array(h, dtype=float))] for h in human_starts],
+            "robot_start_world": [float(x) for x in ct(np.array(robot_start, dtype=float))],
+            "robot_path_world": [nodes_world[str(n)] for n in robot_path],
+            "human_paths_world": [[nodes_world[str(n)] for n in p] for p in human_paths]}
+    assert scen["0"]["robot_start_world"] == out["scenario_0"]["robot_start_world"]
+    assert scen["0"]["human_starts_world"] == out["scenario_0"]["human_starts_world"]
+    out["scenarios"] = scen
+    out["graph_edges"] = [[int(a), int(b)] for a, b in graph["edge_list"]]
+    out["main_base_constants"] = {"HUMAN_SIZE": 0.2, "HUMAN_VMAX": 1.5, "HUMAN_STAGGER": 0.5, "max_run_time_step": 120,
+                                  "note": "class attributes of MainBase (main_base.py:74-77) and main_eva.main's default"}
+    for node in tree.body:        # the class attributes as the reference writes them (checked, not trusted)
+        if isinstance(node, ast.ClassDef) and node.name == "MainBase":
+            vals = {t.targets[0].id: ast.literal_eval(t.value) for t in node.body
+                    if isinstance(t, ast.Assign) and isinstance(t.targets[0], ast.Name) and isinstance(t.value, ast.Constant)}
+            for k_ in ("HUMAN_SIZE", "HUMAN_VMAX", "HUMAN_STAGGER"):
+                assert vals[k_] == out["main_base_constants"][k_], (k_, vals)
     return out
 
 

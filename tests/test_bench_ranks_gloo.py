@@ -64,6 +64,14 @@ def test_bench_rank_logic_two_ranks_gloo(tmp_path):
     # MAX over ranks of the elapsed time: rank 1 sleeps 40 ms per step, rank 0 20 ms
     assert rec["ms_per_step"] >= 40.0 and abs(rec["value"] - 2 * 48 * 3 / (rec["ms_per_step"] * 3e-3)) < 1e-6 * rec["value"] + 1e-3
     assert rec["roofline"]["valu_frac"] > 0 and rec["roofline"]["psi_evals_per_solve"] == 7.0
+    # SCALE day-one diagnostics: did the process group see N ranks, every rank's own time per step
+    # (imbalance between shards), its kernel time, and what the gather costs -- at the top level of the ONE line
+    assert rec["ranks"] == 2 and len(rec["per_rank_ms"]) == 2 and len(rec["per_rank_kernel_ms"]) == 2
+    # (the gather inside a step makes the fast rank wait for the slow one: the ranks' wall times agree; the imbalance between
+    #  the shards shows in their KERNEL times -- rank 1 is the slow one, 40 ms per step against 20)
+    assert all(abs(v - rec["ms_per_step"]) < 0.2 * rec["ms_per_step"] for v in rec["per_rank_ms"])
+    assert rec["per_rank_kernel_ms"] == [20.0, 40.0]
+    assert rec["gather_ms"] >= 0 and rec["gather_bytes_per_rank"] == 48 * 40 * 4
     r0, r1 = (np.load(tmp_path / f"r{r}.npz") for r in range(2))
     assert float(r0["chk"]) != float(r1["chk"])                      # every rank solved its own shard (seed + rank)
     for r in (r0, r1):                                              # gathered = [rank 0's controls; rank 1's], on every rank

@@ -18,6 +18,7 @@ import pytest
 
 import dyobav_mpcnwta_warehouse_amd as nm
 import oracle
+import accuracy_protocol
 from accuracy_protocol import run_case
 
 pytestmark = pytest.mark.gpu
@@ -81,9 +82,14 @@ def check_protocol_row(row, workload, passing, n):
         # the two evaluators agree at every end point (differences relative to |psi|: the gradient there is ~1e-5)
         # (at penalties of 1e9 the gradient is a sum of terms ~ c x 1e-9 that cancel: 1e-16 x c in absolute terms)
         assert k["max_grad_rel_diff_hip_vs_oracle"] < 1e-7 and k["max_psi_rel_diff_hip_vs_oracle"] < 1e-10, k
+        # a `not_kkt` pair is excused only where the penalty has escalated (gamma ~ 1 / c makes the exit test true anywhere)
+        # and its non-stationary end point is non-stationary by BOTH evaluators: a kernel that stops early at a small
+        # penalty cannot hide there -- for every configuration, configs[4] included
+        for kk in (k, kf):
+            assert all(min(r["a"]["penalty"], r["b"]["penalty"]) >= 1e5 and r["rho_nonstationary_by_both"] > accuracy_protocol.RHO_KKT
+                       for r in kk["far_pairs"] if r["kind"] == "not_kkt"), kk["far_pairs"]
         if workload != "cfg4":
             assert k["n_both_kkt"] >= 8 and k["max_abs_du_both_kkt"] < 1e-5, k     # (oracle vs twin: 2e-7)
-            assert all(min(r["a"]["penalty"], r["b"]["penalty"]) >= 1e5 for r in k["far_pairs"] if r["kind"] == "not_kkt"), k["far_pairs"]
             # the HIP kernels leave no larger a share of the tight pairs > 1e-4 apart than the oracle's twin does (+ 2 pairs)
             far = lambda q: q["n_pairs"] - q["n_agree"]
             assert far(k) <= far(kf) + 2, (k, kf)

@@ -1,6 +1,7 @@
-"""GPU tests of the solver options that round 2 added to the C ABI: the two forms of the AKKT residual
-(nmpc_config.akkt_form, SURVEY.md 8a row A10 / ADVICE r1) and the wall-clock budget (yaml max_solver_time ->
-nmpc_config.max_solver_time_us, NotConvergedOutOfTime)."""
+"""GPU tests of the solver options of the C ABI: the two forms of the AKKT residual (nmpc_config.akkt_form, SURVEY.md 8a
+row A10 / ADVICE r1) and the yaml's max_solver_time in its two forms -- the wall-clock budget (nmpc_config.max_solver_time_us)
+and, round 6 / ABI v5, the deterministic evaluation budget (nmpc_config.max_evaluations) that the CPU oracle mirrors
+(orc_options.max_evals): NotConvergedOutOfTime with exactly the oracle's counts."""
 import numpy as np
 import pytest
 
@@ -81,6 +82,92 @@ def test_max_solver_time_budget_yields_out_of_time():
     assert (short["iters"][slow, 1] < ref["iters"][slow, 1]).all()
     assert np.isfinite(short["U"]).all()
     assert set(np.unique(short["status"])) <= {0, 1, 2}
+
+
+def test_evaluation_budget_agrees_exactly_with_the_oracle():
+    """nmpc_config.max_evaluations (the yaml's max_solver_time as a count, ABI v5) against orc_options.max_evals: because the
+    cap is a COUNT, not a clock, HIP and oracle must agree exactly -- status, outer / inner iteration counts and evaluation
+    counts -- wherever their iterate paths agree, i.e. for budgets of a few dozen iterations in fp64 with equal
+    Lipschitz-estimator steps (tests/test_gpu_parity.py: identical paths over <= 10 iterations, then rounding is amplified).
+    Runs for the throughput, the latency and the cooperative kernel (the module's fixture)."""
+    L = nm.scenarios.ParamLayout()
+    pr = oracle.Problem()
+    P = np.concatenate([nm.scenarios.make_batch(40, L, seed=33), nm.scenarios.make_batch(24, L, seed=34, ped_mode="passing")])
+    opts = dict(lip_delta=1e-4, lip_eps=1e-4)
+    with nm.Handle(config_for(pr, lip_delta_f64=1e-4, lip_eps_f64=1e-4)) as h:
+        ref = h.solve(P)
+    for E, need in ((3, 1.0), (25, 1.0), (60, 0.95), (150, 0.8)):     # (measured: 1.0, 1.0, 0.98-1.0, 0.86)
+        Uo, ro = oracle.solve_batch(pr, oracle.Options(max_evals=E, **opts), P, nthreads=8)
+        with nm.Handle(config_for(pr, lip_delta_f64=1e-4, lip_eps_f64=1e-4, max_evaluations=E)) as h:
+            r = h.solve(P)
+        same = ((r["status"] == ro["status"]) & (r["iters"][:, 0] == ro["outer_iters"]) & (r["iters"][:, 1] == ro["inner_iters"]) &
+                (r["info"][:, 4].astype(int) == ro["n_points"]) & (r["info"][:, 5].astype(int) == ro["n_grad_evals"]))
+        assert same.mean() >= need, (E, same.mean(), np.flatnonzero(~same)[:8])
+        du = np.abs(r["U"] - Uo).max(axis=1)
+        # (the paths that take the same decisions stay together: 1e-8 over 25 evaluations, growing with the path length)
+        assert np.quantile(du[same], 0.9) < (1e-8 if E <= 25 else 1e-6) and du[same].max() < (1e-4 if E <= 60 else 0.1), (E, du[same].max())
+        # properties that hold whatever the rounding does
+        n = r["info"][:, 4].astype(int)
+        cut = ref["info"][:, 4] > E + 23
+        assert cut.sum() >= 30 and (r["status"][cut] == 2).all()
+        assert (n[cut] >= E).all() and (n[cut] <= max(E, 3) + 23).all(), (E, n[cut].min(), n[cut].max())
+        assert np.isfinite(r["U"]).all() and set(np.unique(r["status"])) <= {0, 1, 2}
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_evaluation_budget_is_a_property_of_the_instance(dtype):
+    """Unlike the wall-clock cap, the evaluation budget does not depend on the clock, the batch or the launch structure:
+    a generous budget changes nothing bit for bit; the budgeted result is the same for a subset / permutation of the
+    batch, for the one-launch and the staged (resumable) solve, and -- latency kernel -- for any number of wavefronts."""
+    lay = nm.scenarios.ParamLayout()
+    P = np.concatenate([nm.scenarios.make_batch(96, lay, seed=35), nm.scenarios.make_batch(96, lay, seed=36, ped_mode="passing")]).astype(dtype)
+    pr = oracle.Problem()
+    keys = ("U", "cost", "status", "iters", "info")
+    E = 500
+    with nm.Handle(config_for(pr)) as h:
+        ref = h.solve(P, dtype=dtype)
+    with nm.Handle(config_for(pr, max_evaluations=10**9)) as h:
+        big = h.solve(P, dtype=dtype)
+    for k in keys:
+        assert np.array_equal(big[k], ref[k], equal_nan=True), k
+    res = {}
+    for staged in (-1, 1, 2):
+        with nm.Handle(config_for(pr, max_evaluations=E, staged=staged)) as h:
+            res[staged] = h.solve(P, dtype=dtype)
+            assert h.last_launch_info()["staged_outer_iterations"] == max(staged, 0)   # (the budget survives the stage boundary)
+    for k in keys:
+        for staged in (1, 2):
+            if k == "info":     # (info[6], info[7]: exchange rounds / wavefront count -- launch diagnostics, not results)
+                assert np.array_equal(res[staged][k][:, :6], res[-1][k][:, :6]), (k, staged)
+            else:
+                assert np.array_equal(res[staged][k], res[-1][k]), (k, staged)
+    r = res[-1]
+    n = r["info"][:, 4].astype(int)
+    cut = ref["info"][:, 4] > E + 23
+    assert cut.sum() >= 40 and (r["status"][cut] == 2).all() and (n[cut] >= E).all() and (n[cut] <= E + 23).all()
+    done = ref["info"][:, 4] < E                      # finished inside the budget: the unbudgeted result, bit for bit
+    assert done.sum() >= 20
+    for k in ("U", "cost", "status", "iters"):
+        assert np.array_equal(r[k][done], ref[k][done]), k
+    rng = np.random.default_rng(5)
+    sub = rng.permutation(len(P))[:70]
+    with nm.Handle(config_for(pr, max_evaluations=E, staged=-1)) as h:
+        rs = h.solve(np.ascontiguousarray(P[sub]), dtype=dtype)
+    for k in ("U", "cost", "status", "iters"):
+        assert np.array_equal(rs[k], r[k][sub]), k
+    if conftest.KERNEL_MODE["latency_waves"] > 1:
+        for W in (2, 3):
+            cfg = config_for(pr, max_evaluations=E, staged=-1)
+            cfg.latency_waves = W
+            with nm.Handle(cfg) as h:
+                rw = h.solve(P, dtype=dtype)
+            for k in ("U", "cost", "status", "iters"):
+                assert np.array_equal(rw[k], r[k]), (W, k)
+
+
+def test_evaluation_budget_is_validated():
+    with pytest.raises(nm.NmpcError):
+        nm.Handle(config_for(oracle.Problem(), max_evaluations=-1))
 
 
 def test_dispatch_order_changes_nothing_but_the_launch_time():

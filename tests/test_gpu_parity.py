@@ -87,6 +87,9 @@ def test_iterate_path_matches_oracle_f64(family):
         assert np.array_equal(r["iters"][:, 1], ro["inner_iters"])
         assert np.array_equal(r["status"], ro["status"])
         assert np.array_equal(r["info"][:, 5].astype(int), ro["n_grad_evals"])
+        # (round 6) ... and the evaluated points: info[4] = orc_result.n_points, the quantity nmpc_config.max_evaluations /
+        # orc_options.max_evals budget
+        assert np.array_equal(r["info"][:, 4].astype(int), ro["n_points"])
         du = np.abs(r["U"] - Uo).max(axis=1)
         assert np.quantile(du, 0.9) < 1e-9, (family, max_inner, du.max())
         assert du.max() < 1e-6, (family, max_inner, du.max())

@@ -14,6 +14,7 @@ from dyobav_mpcnwta_warehouse_amd.motion_model import UnicycleModel, unicycle_mo
 from dyobav_mpcnwta_warehouse_amd.trajectory_tracker import TrajectoryTracker
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
 CFG = os.path.join(ROOT, "config", "mpc_fast.yaml")
 
 
@@ -144,3 +145,49 @@ def test_closed_loop_scenarios_are_deterministic_and_well_formed():
     with __import__("pytest").raises(AssertionError):
         from dyobav_mpcnwta_warehouse_amd.scenarios import ParamLayout, make_batch
         make_batch(2, ParamLayout(20, 10, 10, 15), n_ped=4, n_hyp=10)       # 40 rows do not fit Ndynobs = 15
+
+
+def test_reference_scenarios_are_the_reference_s_own_geometry():
+    """scenarios.make_reference_scenarios (round 6): run b of the batch is the reference's scenario_{b % 3} -- start state, node
+    path and pedestrian exactly as tests/golden/make_golden.py recorded them from main_base.py:36-58 through the reference's
+    transform -- on the 55 static rectangles of its warehouse map; the other pedestrians walk seeded node paths of the same
+    graph. Deterministic; a batch is a prefix of every larger batch with the same seed. The package's copy of the warehouse
+    data is the golden file, byte for byte. (No GPU: the generator is host-side numpy.)"""
+    import filecmp
+    import numpy as np
+    from dyobav_mpcnwta_warehouse_amd import scenarios
+    pkg = os.path.join(ROOT, "dyobav-mpcnwta-warehouse_amd", "data", "warehouse_world.json")
+    assert filecmp.cmp(pkg, os.path.join(GOLDEN, "warehouse_world.json"), shallow=False)
+    ec = json.load(open(os.path.join(GOLDEN, "evaluate_cases.json")))
+    w = scenarios.warehouse_world()
+    assert w["scenarios"] == ec["scenarios"] and w["nodes_world"] == ec["scenario_0"]["nodes_world"]
+    assert len(w["map_polygons_world"]) == 55 and len(w["nodes_world"]) == 32 and len(w["graph_edges"]) == 55
+    assert w["constants"]["HUMAN_STAGGER"] == scenarios.HUMAN_STAGGER == 0.5 and w["constants"]["HUMAN_VMAX"] == 1.5
+    a = scenarios.make_reference_scenarios(60, seed=13, n_ped=4)
+    b = scenarios.make_reference_scenarios(24, seed=13, n_ped=4)
+    c = scenarios.make_reference_scenarios(60, seed=14, n_ped=4)
+    for k in ("robot_starts", "human_starts", "human_paths", "scenario_index"):
+        assert np.array_equal(a[k][:24], b[k]), k
+    assert a["robot_paths"][:24] == b["robot_paths"] and not np.array_equal(a["human_starts"], c["human_starts"])
+    assert a["map_polygons"].shape == (55, 4, 2) and a["human_starts"].shape == (60, 4, 2) and a["human_paths"].shape == (60, 4, 4, 2)
+    nodes = {tuple(v) for v in w["nodes_world"].values()}
+    edges = {frozenset((tuple(w["nodes_world"][str(x)]), tuple(w["nodes_world"][str(y)]))) for x, y in w["graph_edges"]}
+    for i in range(60):
+        s = w["scenarios"][str(i % 3)]
+        assert a["scenario_index"][i] == i % 3
+        assert a["robot_starts"][i].tolist() == s["robot_start_world"]                    # main_base.py:136 ct2real(ROBOT_START_POINT)
+        assert [list(p) for p in a["robot_paths"][i]] == s["robot_path_world"]             # :138 the node list, in world coordinates
+        assert a["human_starts"][i, 0].tolist() == s["human_starts_world"][0]              # the scenario's own pedestrian ...
+        own = s["human_paths_world"][0]
+        assert a["human_paths"][i, 0].tolist() == (own + [own[-1]] * 4)[:4]                # ... on its own node path (padded)
+        for h in range(1, 4):                                                              # the others: walks along graph edges
+            path = [tuple(p) for p in a["human_paths"][i, h].tolist()]
+            assert all(p in nodes for p in path)
+            first = min(nodes, key=lambda n: np.hypot(n[0] - a["human_starts"][i, h, 0], n[1] - a["human_starts"][i, h, 1]))
+            assert np.abs(np.array(first) - a["human_starts"][i, h]).max() <= 0.5
+            walk = [first] + path
+            assert all(frozenset((walk[j], walk[j + 1])) in edges for j in range(4))
+            assert all(walk[j + 2] != walk[j] or len({frozenset((walk[j + 1], n)) for n in nodes} & edges) == 1 for j in range(3))
+            assert np.hypot(*(a["human_starts"][i, h] - a["robot_starts"][i, :2])) >= 2.3   # not on top of the robot
+    one = scenarios.make_reference_scenarios(9, seed=1, scenario=2)
+    assert (one["scenario_index"] == 2).all() and one["robot_starts"][:, 0].tolist() == [w["scenarios"]["2"]["robot_start_world"][0]] * 9

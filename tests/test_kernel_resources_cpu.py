@@ -75,7 +75,10 @@ def test_fp32_latency_and_cooperative_kernels_spill_little(resources):
         assert r["sgpr_spill"] <= 52, (name, r)
         # (general path of the register-table variants: up to 23 VGPRs in scratch; the axis-aligned members: 0 / 9 dwords)
         mid = re.search(r"<float, 3, false, 6, (1|2)>", name)       # (6-slot kernels: 16 / 32 VGPRs in scratch, see above)
-        assert r["scratch"] <= ((72 if mid.group(1) == "1" else 168) if mid else 96 if general else 40 if axis else 0), (name, r)
+        # (round 6: an LDS-table member may carry the same unused 9-dword frame object as the 14-slot axis member: private
+        #  segment 36 B with NO spilled vector register and NO scratch instruction in its code -- checked on the disassembly)
+        phantom = r["scratch"] == 36 and r["vgpr_spill"] == 0 and r["scratch_instr"] == 0
+        assert phantom or r["scratch"] <= ((72 if mid.group(1) == "1" else 168) if mid else 96 if general else 40 if axis else 0), (name, r)
     sel = _sel(resources, r"solve_coop(_reg)?_kernel<(float|true|false)")
     assert any("coop_reg" in n for n in sel)          # (the on-chip kernels are named <true> / <false>: they must not drop out)
     for name, r in sel.items():

@@ -31,6 +31,18 @@ def kernel_resources(lib=DEFAULT_LIB):
         notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True,
                                text=True).stdout
         syms = subprocess.run(["nm", "-S", co], check=True, capture_output=True, text=True).stdout
+        # kernels that reserve a private segment without spilling a vector register: how many scratch instructions do they
+        # really execute? (the backend sometimes reserves a 9-dword frame object next to the SGPR-spill lanes and never
+        # touches it: private_segment_fixed_size 36, no scratch_* / buffer_* instruction in the kernel)
+        phantom = {}
+        for b in re.split(r"\n\s+- \.", notes[notes.find("amdhsa.kernels"):])[1:]:
+            b = "." + b
+            n = re.search(r"\.name:\s+(\S+)", b)
+            g = lambda k: int((re.search(r"\.%s:\s+(\d+)" % k, b) or [None, "-1"])[1])
+            if n and g("private_segment_fixed_size") > 0 and g("vgpr_spill_count") == 0:
+                dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn",
+                                      f"--disassemble-symbols={n.group(1)}", co], check=True, capture_output=True, text=True).stdout
+                phantom[n.group(1)] = len(re.findall(r"^\s+(scratch_|buffer_load|buffer_store)", dis, flags=re.M))
     size = {}   # mangled kernel name -> bytes of code
     for line in syms.splitlines():
         m = re.match(r"[0-9a-f]+ ([0-9a-f]+) [Tt] (\S+)$", line)
@@ -48,7 +60,9 @@ def kernel_resources(lib=DEFAULT_LIB):
         rows[n.group(1)] = dict(vgpr=g("vgpr_count"), agpr=g("agpr_count"), sgpr=g("sgpr_count"),
                                 vgpr_spill=g("vgpr_spill_count"), sgpr_spill=g("sgpr_spill_count"),
                                 scratch=g("private_segment_fixed_size"), lds_static=g("group_segment_fixed_size"),
-                                code_bytes=size.get(n.group(1), -1))
+                                code_bytes=size.get(n.group(1), -1),
+                                # scratch instructions in the kernel's code; counted only where it matters (see above), else -1
+                                scratch_instr=phantom.get(n.group(1), -1))
     return {d: rows[m] for m, d in zip(names, demangle(names))}
 
 
