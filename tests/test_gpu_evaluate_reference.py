@@ -185,7 +185,7 @@ def test_config0_scenario_0_driven_by_the_oracle_against_the_kernels(cases):
                                      initial_penalty=c.initial_penalty, penalty_update=c.penalty_update_factor,
                                      inner_tol_update=c.inner_tolerance_update_factor, sufficient_decrease=c.sufficient_decrease_coeff,
                                      lip_delta=c.lip_delta_f64, lip_eps=c.lip_eps_f64, cbfgs_alpha=c.cbfgs_alpha,
-                                     cbfgs_eps=c.cbfgs_epsilon, sy_eps=c.sy_epsilon, akkt_form=c.akkt_form)
+                                     cbfgs_eps=c.cbfgs_epsilon, sy_eps=c.sy_epsilon, akkt_form=c.akkt_form, max_evals=c.max_evaluations, hoist_trig=1)
             self.reassoc = reassoc
             self.y = None
             self.n_converged = self.n_calls = 0

@@ -108,9 +108,9 @@ def test_evaluation_budget_agrees_exactly_with_the_oracle():
         assert np.quantile(du[same], 0.9) < (1e-8 if E <= 25 else 1e-6) and du[same].max() < (1e-4 if E <= 60 else 0.1), (E, du[same].max())
         # properties that hold whatever the rounding does
         n = r["info"][:, 4].astype(int)
-        cut = ref["info"][:, 4] > E + 23
+        cut = ref["info"][:, 4] > E + 45       # (overshoot: <= two iterations of <= 22 evaluations + F1 / F2, nmpc_hip.h)
         assert cut.sum() >= 30 and (r["status"][cut] == 2).all()
-        assert (n[cut] >= E).all() and (n[cut] <= max(E, 3) + 23).all(), (E, n[cut].min(), n[cut].max())
+        assert (n[cut] >= E).all() and (n[cut] <= max(E, 3) + 45).all(), (E, n[cut].min(), n[cut].max())
         assert np.isfinite(r["U"]).all() and set(np.unique(r["status"])) <= {0, 1, 2}
 
 
@@ -143,8 +143,8 @@ def test_evaluation_budget_is_a_property_of_the_instance(dtype):
                 assert np.array_equal(res[staged][k], res[-1][k]), (k, staged)
     r = res[-1]
     n = r["info"][:, 4].astype(int)
-    cut = ref["info"][:, 4] > E + 23
-    assert cut.sum() >= 40 and (r["status"][cut] == 2).all() and (n[cut] >= E).all() and (n[cut] <= E + 23).all()
+    cut = ref["info"][:, 4] > E + 45
+    assert cut.sum() >= 40 and (r["status"][cut] == 2).all() and (n[cut] >= E).all() and (n[cut] <= E + 45).all()
     done = ref["info"][:, 4] < E                      # finished inside the budget: the unbudgeted result, bit for bit
     assert done.sum() >= 20
     for k in ("U", "cost", "status", "iters"):

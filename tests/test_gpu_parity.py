@@ -276,6 +276,33 @@ def test_config4_long_horizon_obstacle_table_streamed_from_global_memory():
     assert np.abs(r["U"] - Uo).max() < 1e-6
 
 
+def test_streamed_table_kernel_pair_members_agree_to_rounding():
+    """The two members of the streamed-table kernel pair on the SAME batch: the compressed member forms its
+    inverse squared radii by v_rcp + Newton steps (not correctly rounded), the general member stores IEEE quotients -- they
+    agree to rounding (1e-13 of |psi| in fp64), not bit for bit, which is why `axis_aligned = 0` (the member is chosen per
+    CALL) makes an instance's last bits depend on the batch and callers that need batch-independent results pin 1 or -1
+    (nmpc_hip.h). A radius so large that its square overflows is simply out of reach for both members (fast_rcp clamps its
+    argument: the Newton step of an infinity would be NaN)."""
+    lay = nm.scenarios.ParamLayout(40, 10, 10, 160)
+    P = nm.scenarios.make_batch(8, lay, seed=6, n_ped=8, n_hyp=20, ped_mode="oncoming")
+    pr = oracle.Problem(40, 10, 10, 160)
+    rng = np.random.default_rng(10)
+    U = np.stack([rng.uniform(-0.5, 1.5, (8, 40)), rng.uniform(-0.5, 0.5, (8, 40))], axis=2).reshape(8, 80)
+    Y, C = rng.normal(size=(8, 80)), rng.uniform(1, 100, 8)
+    res = {}
+    for dt, big in ((np.float64, 1e200), (np.float32, 1e30)):
+        Pd = P.copy()
+        Pd[7, lay.od + 6 * (3 * 41 + 5) + 2] = big          # one radius whose square overflows: (rx + 1e-6)^2 = inf
+        for axis in (1, -1):
+            with nm.Handle(config_for(pr, coop_waves=4, latency_waves=1, reg_table=-1, axis_aligned=axis)) as h:
+                res[axis] = h.eval(Pd, U, Y, C, dtype=dt)
+        tol = 1e-12 if dt == np.float64 else 2e-5
+        assert np.isfinite(res[1]["psi"]).all() and np.isfinite(res[-1]["psi"]).all() and np.isfinite(res[1]["grad"]).all()
+        np.testing.assert_allclose(res[1]["psi"], res[-1]["psi"], rtol=tol)
+        scale = np.abs(res[-1]["grad"]).max(axis=1, keepdims=True)
+        assert (np.abs(res[1]["grad"] - res[-1]["grad"]) <= 10 * tol * scale).all()
+
+
 @pytest.mark.parametrize("axis", [0, 1, -1])
 def test_config4_compressed_global_table(axis):
     """The COMPRESSED streamed table of the cooperative global-table kernels (round 5; nmpc_device.h Instance::CMP): for

@@ -102,12 +102,13 @@ def test_oracle_evaluation_budget_is_deterministic_and_counts_like_the_kernels()
         U1, r1 = oracle.solve_batch(pr, oracle.Options(max_evals=E), P, nthreads=4)
         U2, r2 = oracle.solve_batch(pr, oracle.Options(max_evals=E), P, nthreads=1)          # deterministic: threads, order
         assert np.array_equal(U1, U2) and np.array_equal(r1["n_points"], r2["n_points"])
-        cut = r0["n_points"] > E + 22
+        cut = r0["n_points"] > E + 45
         assert cut.any() or E == 2500
-        # cut off: status 2, the budget overshot by at most the iteration in progress (1 + 10 Lipschitz + 11 line-search
-        # evaluations) + the F1 / F2 evaluation behind it; never more work than the unbudgeted solve
+        # cut off: status 2, the budget overshot by at most two iterations (1 + 10 Lipschitz + 11 line-search evaluations
+        # each: like OpEn's `while step() && flags`, the step that follows the failed test still runs) + the F1 / F2
+        # evaluation behind them; never more work than the unbudgeted solve
         assert (r1["status"][cut] == 2).all()
-        assert (r1["n_points"][cut] >= E).all() and (r1["n_points"][cut] <= max(E, 3) + 23).all(), (E, r1["n_points"][cut])
+        assert (r1["n_points"][cut] >= E).all() and (r1["n_points"][cut] <= max(E, 3) + 45).all(), (E, r1["n_points"][cut])
         assert (r1["n_points"] <= r0["n_points"]).all()
         # not cut off (finished within the budget): identical to the unbudgeted solve
         free = r0["n_points"] < E
@@ -117,7 +118,7 @@ def test_oracle_evaluation_budget_is_deterministic_and_counts_like_the_kernels()
         Ur, rr = oracle.solve_batch(pr, oracle.Options(max_evals=E), P, nthreads=4, reassoc=True)
         assert (rr["status"][cut] == 2).all()
     U32, r32 = oracle.solve_batch(pr, oracle.Options(max_evals=400, lip_delta=1e-4, lip_eps=1e-4), P, nthreads=4, dtype=np.float32)
-    assert (r32["n_points"] <= 423).all() and ((r32["status"] == 2) | (r32["n_points"] < 400)).all()
+    assert (r32["n_points"] <= 445).all() and ((r32["status"] == 2) | (r32["n_points"] < 400)).all()
 
 
 def test_evaluation_budget_from_the_yaml_time_cap():
@@ -143,3 +144,25 @@ def test_evaluation_budget_from_the_yaml_time_cap():
         assert cfg.max_evaluations == 0 and cfg.max_solver_time_us == 0.0
     with pytest.raises(ValueError):
         make_config(time_cap="sometimes")
+
+
+def test_hoisted_trigonometry_gives_the_same_bits():
+    """orc_options.hoist_trig = 1 (cos / sin of the ellipse angles once per solve instead of on every evaluation, as a hand-tuned
+    CPU solver would; the default recomputes them like the reference's CasADi-generated code) changes the time, not one bit of
+    the result -- controls, statuses, every count -- for axis-aligned and rotated ellipses, in fp64, in the re-associated twin and
+    in fp32. It is the CPU-baseline speed option of bench.py (`value_trig_hoisted`) and what the GPU suite's CPU-bound legs use."""
+    for dims, n in (((20, 10, 10, 15), 10), ((20, 10, 10, 40), 6)):
+        lay = nm.scenarios.ParamLayout(*dims)
+        P = nm.scenarios.make_batch(n, lay, seed=17, n_ped=dims[3] // 5, n_hyp=5, ped_mode="passing")
+        rows = P[:, lay.od:lay.od + lay.Ndyn * (lay.N + 1) * 6].reshape(n, lay.Ndyn, lay.N + 1, 6)
+        rows[n // 2:, ::2, :, 4] = 0.37                       # half of the instances: every other ellipse rotated
+        pr = oracle.Problem(*dims)
+        for kw in (dict(), dict(reassoc=True), dict(dtype=np.float32)):
+            opts = dict(lip_delta=1e-4, lip_eps=1e-4) if kw.get("dtype") is np.float32 else {}
+            U0, r0 = oracle.solve_batch(pr, oracle.Options(**opts), P, nthreads=4, **kw)
+            U1, r1 = oracle.solve_batch(pr, oracle.Options(hoist_trig=1, **opts), P, nthreads=4, **kw)
+            assert np.array_equal(U0, U1), (dims, kw)
+            assert all(np.array_equal(r0[k], r1[k]) for k in r0.dtype.names), (dims, kw)
+        u, y, res, head, Ut = oracle.solve_trace(pr, oracle.Options(hoist_trig=1), P[-1])
+        u0, y0, res0, head0, Ut0 = oracle.solve_trace(pr, oracle.Options(), P[-1])
+        assert np.array_equal(u, u0) and np.array_equal(head, head0) and np.array_equal(Ut, Ut0)

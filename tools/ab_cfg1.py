@@ -1,5 +1,5 @@
 import json, os, subprocess, sys
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CODE = r'''
 import json, os, sys
 sys.path.insert(0, %r)

@@ -2,8 +2,9 @@
 """The noise-floor / first-divergence / tight-tolerance KKT protocol of tests/accuracy_protocol.py on larger samples than
 the test-suite runs (TEST INFRASTRUCTURE: imports the oracle).
    usage: audit_large.py [n] [n_tight] [families: passing closed_loop ...]
-   `passing`: configs[1] and configs[2] generators; `closed_loop`: parameter vectors harvested from the closed loop at
-   configs[2]'s dimensions (scenarios.harvest_closed_loop). Every far pair is audited (no truncation)."""
+   `passing`: configs[1] and configs[2] generators; `closed_loop` / `refscen`: parameter vectors harvested from the closed loop
+   at configs[2]'s dimensions (scenarios.harvest_closed_loop: the corridor family / the reference's scenario_0..2 on its
+   warehouse map). Every far pair is audited (no truncation); TIGHT_AUDIT=1: the tolerance-1e-8 pairs too."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -33,14 +34,22 @@ def digest(row, wl, fam):
 
 
 for fam in families:
-    if fam == "closed_loop":
+    if fam in ("closed_loop", "refscen"):
         lay = nm.scenarios.BENCH_CONFIGS["cfg2_b65536_n20_4x10"]["layout"]
         cfg = nm.default_config_struct()
         cfg.Ndynobs, cfg.max_active_dynobs = lay.Ndyn, 40
-        P, _ = nm.scenarios.harvest_closed_loop(cfg, max(3 * n // 2, 96), steps=(1, 8, 20), seed=13, n_ped=4, n_hyp=10, dtype=np.float32)
-        row = ap.run_case_on(nm, oracle, P[:n].astype(np.float64), lay, 40, "cfg2", "closed_loop", nthreads=16, tight=n_tight > 0,
-                             audit=True, audit_max=10 ** 6, tight_audit=False, n_tight=n_tight or None, polish=False)
-        print(json.dumps(digest(row, "cfg2", fam)), flush=True)
+        steps, hfam = ((1, 8, 20), "corridor") if fam == "closed_loop" else ((2, 14, 26), "reference")
+        P, _ = nm.scenarios.harvest_closed_loop(cfg, max(3 * n // 2, 96), steps=steps, seed=13, n_ped=4, n_hyp=10, dtype=np.float32, family=hfam)
+        tight_audit = bool(os.environ.get("TIGHT_AUDIT"))
+        row = ap.run_case_on(nm, oracle, P[:n].astype(np.float64), lay, 40, "cfg2", fam, nthreads=16, tight=n_tight > 0,
+                             audit=True, audit_max=10 ** 6, tight_audit=tight_audit, n_tight=n_tight or None, polish=False)
+        d = digest(row, "cfg2", fam)
+        if tight_audit and "divergence_audit_tight" in row:
+            ta = row["divergence_audit_tight"]
+            d["tight_audit_hip_vs_oracle"] = {k: v for k, v in ta.items() if k not in ("pairs", "oracle_vs_reassociated")}
+            d["tight_audit_oracle_vs_reassociated"] = {k: v for k, v in ta["oracle_vs_reassociated"].items() if k != "pairs"}
+            d["tight_unexplained_pairs"] = [p for p in ta["pairs"] if not p["explained"]]
+        print(json.dumps(d), flush=True)
         continue
     for wl in ("cfg1", "cfg2"):
         row = ap.run_case(nm, oracle, wl, fam, n=n, nthreads=16, tight=n_tight > 0, audit=True, audit_max=10 ** 6, tight_audit=False,

@@ -1,5 +1,6 @@
 import sys, numpy as np
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dyobav_mpcnwta_warehouse_amd as nm
 spec = dict(nm.scenarios.BENCH_CONFIGS["cfg1_b1024_n20_2x5"]); lay = spec.pop("layout"); spec.pop("B")
 for B in (64, 256):

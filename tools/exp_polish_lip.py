@@ -1,5 +1,6 @@
 import json, os, sys
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import dyobav_mpcnwta_warehouse_amd as nm
 key = "cfg2_b65536_n20_4x10"

@@ -1,5 +1,6 @@
 import json, sys
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 class A: gpus = 1
 env = bench.Env(A())
