@@ -278,7 +278,10 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
     achieved_gbs = bytes_per_solve * B / (k_ms * 1e-3) / 1e9
     ff = flops_forward(layout.N, layout.Nother, layout.Nstc, layout.Ndyn)
     n_psi, n_grad = info[:, 4], info[:, 5]
-    waves = int(info[0, 7])          # 0: throughput kernel; > 0: latency kernel with that many wavefronts per instance
+    # 0: throughput kernel; > 0: latency kernel with that many wavefronts per instance; < 0: cooperative. (By the launch's family:
+    # under the tail hand-off a throughput launch has a few rows with info[7] = 4 -- the instances the latency family solved.)
+    fam_l = launch.get("family", "throughput")
+    waves = 0 if fam_l == "throughput" else int(info[:, 7].max()) if fam_l == "latency" else int(info[:, 7].min())
     tname = "float" if dtype == "f32" else "double"
     lps = kinfo["lanes_per_step"]
     # short name for the line: the rocprofv3 kernel-trace name (register-table kernels are pairs: <.., slots, 1> = the
@@ -298,7 +301,7 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
     ctail = f",true,{member}" if (glb and member and waves == -4) else ""
     if dtype == "f64" and not tail and lps == 3 and waves == 0 and member and launch["axis_aligned"] >= 0:
         tail = f",false,14,{member}"                 # (the fp64 register-table kernel: one wavefront per SIMD, 14 slots)
-    kernel_name = (f"solve_spec_kernel<{tname},{lps}{tail}> W={waves}" if waves > 0
+    kernel_name = (f"solve_spec_kernel<{tname},{lps}{tail or ',false,0,0'},true> W={waves}" if waves > 0
                    else f"solve_coop_reg_kernel<{'true' if 33 <= layout.N <= 42 else 'false'}> W=8" if waves == -8
                    else f"solve_coop_kernel<{tname},{lps}{ctail}> W={-waves}" if waves < 0
                    else f"solve_kernel<{tname},{lps}{tail}>")
@@ -310,6 +313,8 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
     conv = status == 0
     if launch["axis_aligned"] == 2:
         kernel_desc += "; axis-aligned member of the kernel pair chosen on the device (the general twin returns at once)"
+    if launch.get("tail_handed_off"):
+        kernel_desc += f"; tail hand-off: the {launch['tail_handed_off']} instances ranked longest solved by the latency family's tail member (same bits) next to it"
     if launch["staged_outer_iterations"]:
         kernel_name += " x2 launches"
         kernel_desc += f"; two launches: pilot of {launch['staged_outer_iterations']} outer iteration(s), rest ranked by ||F2||"
@@ -332,7 +337,7 @@ def run_workload(env: Env, workload: str, family: str, dtype: str, steps: int, w
         "config": {"workload": f"{workload}: {desc}", "family": family, "batch_per_gpu": B, "N_hor": layout.N,
                    "Ndynobs": layout.Ndyn, "Nstcobs": layout.Nstc, "Nother": layout.Nother, "np": layout.np_,
                    "max_active_dynobs": int(cfg.max_active_dynobs), "latency_waves": int(cfg.latency_waves),
-                   "max_evaluations": int(getattr(cfg, "max_evaluations", 0)),
+                   "max_evaluations": int(getattr(cfg, "max_evaluations", 0)), "tail_handed_off": int(launch.get("tail_handed_off", 0)),
                    "dispatch": ("longest first by the evaluation counts of a previous pass over the same batch"
                                 if dispatch_hint else "index order"),
                    "lds_bytes_per_instance": int(kinfo["lds_bytes_" + dtype]),
@@ -512,7 +517,7 @@ def accuracy_digest(acc) -> dict:
 def compact_line(detail: dict) -> str:
     """The ONE stdout line: driver keys, `roofline`, `cpu_baseline` and flat digests -- numbers, no prose. Optional parts
     are dropped (largest first) should the line ever exceed LINE_TARGET_BYTES; above LINE_LIMIT_BYTES is an error."""
-    keep_cfg = ("workload", "family", "batch_per_gpu", "N_hor", "Ndynobs", "max_active_dynobs", "Nstcobs", "Nother", "np", "dispatch",
+    keep_cfg = ("workload", "family", "batch_per_gpu", "N_hor", "Ndynobs", "max_active_dynobs", "tail_handed_off", "Nstcobs", "Nother", "np", "dispatch",
                 "sharding")
     keep_roof = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_launch",
                  "valu_tflops", "valu_peak_tflops", "valu_frac", "psi_evals_per_solve", "flops_per_psi_eval")

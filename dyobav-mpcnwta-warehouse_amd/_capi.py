@@ -47,7 +47,7 @@ class NmpcConfigStruct(C.Structure):
         ("polish", C.c_int32), ("polish_max_outer_iterations", C.c_int32), ("polish_max_inner_iterations", C.c_int32),
         ("staged_evals", C.c_int32),
         ("polish_tolerance", C.c_double), ("polish_delta_tolerance", C.c_double),
-        ("max_evaluations", C.c_int32), ("reserved0", C.c_int32),
+        ("max_evaluations", C.c_int32), ("tail_latency", C.c_int32),
     ]
 
 
@@ -264,7 +264,7 @@ class Handle:
         v = (C.c_int32 * 8)()
         _check(self._lib.nmpc_last_launch_info(self._h, C.byref(v)))
         return {"family": ("throughput", "latency", "cooperative")[v[0]], "axis_aligned": int(v[1]),
-                "staged_outer_iterations": int(v[2]), "polish_selected": int(v[3])}
+                "staged_outer_iterations": int(v[2]), "polish_selected": int(v[3]), "tail_handed_off": int(v[4])}
 
     def kernel_info(self) -> dict:
         v = [C.c_int32() for _ in range(5)]

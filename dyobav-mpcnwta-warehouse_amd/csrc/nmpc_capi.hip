@@ -236,6 +236,7 @@ struct nmpc_handle_s {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int last_tail = 0;              // tail hand-off of the last solve: the parking threshold it ran with (0 = none)
     bool timed = false;
     int ptr_mode = NMPC_PTR_DETECT;
     DevBuf dP, dU, dcost, dstatus, diters, du0, dy, dc0, dinfo, dY2, dC2, dpsi, dgrad, df2, dws;
@@ -331,7 +332,8 @@ __global__ __launch_bounds__(64 * kCoopRegWaves, 2) void solve_coop_reg_kernel(n
 }
 
 // latency mode: kSpecWaves wavefronts per instance, speculative line search (nmpc_spec.h)
-template <typename T, int LPS, bool GLB, int RS = 0, int ONLY = 0>
+// FLAT = false: the TAIL member (nmpc_spec.h) -- this kernel with the throughput kernels' evaluation, bit-identical to them
+template <typename T, int LPS, bool GLB, int RS = 0, int ONLY = 0, bool FLAT = true>
 __global__ __launch_bounds__(64 * kSpecWavesMax, (wpe<T, RS>(NMPC_SPEC_WPE_F32))) void solve_spec_kernel(nmpc::KParams<T> kp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -341,14 +343,14 @@ __global__ __launch_bounds__(64 * kSpecWavesMax, (wpe<T, RS>(NMPC_SPEC_WPE_F32))
         const int inst = nmpc::dispatch_index(kp);
         if (nmpc::finished_in_pilot<T>(inst)) return;
         if (ONLY != 2 && axis) {
-            nmpc::solve_instance_spec<T, LPS, GLB, RS, true>(kp, inst, reinterpret_cast<T*>(smem));
+            nmpc::solve_instance_spec<T, LPS, GLB, RS, true, FLAT>(kp, inst, reinterpret_cast<T*>(smem));
             return;
         }
-        if constexpr (ONLY != 1) nmpc::solve_instance_spec<T, LPS, GLB, RS>(kp, inst, reinterpret_cast<T*>(smem));
+        if constexpr (ONLY != 1) nmpc::solve_instance_spec<T, LPS, GLB, RS, false, FLAT>(kp, inst, reinterpret_cast<T*>(smem));
     } else {
         const int inst = nmpc::dispatch_index(kp);
         if (nmpc::finished_in_pilot<T>(inst)) return;
-        nmpc::solve_instance_spec<T, LPS, GLB, RS>(kp, inst, reinterpret_cast<T*>(smem));
+        nmpc::solve_instance_spec<T, LPS, GLB, RS, false, FLAT>(kp, inst, reinterpret_cast<T*>(smem));
     }
 }
 
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(256) void axis_scan_kernel(const T* P, int np, int 
 
 // Resumable solve, ranking of the next launch: counting sort, descending, of a key the parked state holds -- key 0: the
 // hard-constraint violation ||F2|| (bucket = the top 10 bits of the float: monotonic for values >= 0), key 1: the psi
-// evaluations used so far (64 per bucket). Finished instances go to bucket 0.
+// evaluations used so far (64 per bucket). Finished instances -- and only they -- go to bucket 0.
 constexpr int kRankBuckets = 1024;
 template <typename T>
 __device__ __forceinline__ int rank_bucket(const T* resume, const int* status, int b, int key)
@@ -425,7 +427,9 @@ __device__ __forceinline__ int rank_bucket(const T* resume, const int* status, i
     } else {
         bits = (unsigned)((int)sc[7]) >> 6;
     }
-    return (int)(bits < (unsigned)kRankBuckets ? bits : kRankBuckets - 1);
+    // (an unfinished instance never shares bucket 0 with the finished ones -- ||F2|| = 0 is common: no obstacle in reach --:
+    //  the launch that follows counts on the unfinished instances standing FIRST in its order, and on their number, offs[0])
+    return (int)(bits < 1u ? 1u : bits < (unsigned)kRankBuckets ? bits : (unsigned)kRankBuckets - 1u);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void rank_hist_kernel(const T* resume, const int* status, int B, int* hist, int key)
@@ -438,9 +442,11 @@ __global__ __launch_bounds__(256) void rank_hist_kernel(const T* resume, const i
     if (q > 0) atomicAdd(&hist[q], 1);
     else if (q == 0 && (int)(threadIdx.x & 63) == __ffsll((long long)m0) - 1) atomicAdd(&hist[0], __popcll(m0));
 }
+// (tail hand-off under a caller's dispatch order, no ranking before the launch: all B instances are to be solved)
+__global__ void dyn_init_kernel(int* dyn_ctr, int total) { dyn_ctr[0] = 0, dyn_ctr[1] = 0, dyn_ctr[2] = total; }
 // offs[q] = number of instances in buckets above q (one workgroup of kRankBuckets threads; reversed inclusive scan)
 // (the counters are left zeroed for the next ranking: no memset between launches)
-__global__ __launch_bounds__(kRankBuckets) void rank_scan_kernel(int* hist, int* offs)
+__global__ __launch_bounds__(kRankBuckets) void rank_scan_kernel(int* hist, int* offs, int* dyn_ctr)
 {
     __shared__ int sh[kRankBuckets];
     const int t = threadIdx.x;                 // t = 0 is the top bucket
@@ -455,6 +461,8 @@ __global__ __launch_bounds__(kRankBuckets) void rank_scan_kernel(int* hist, int*
         __syncthreads();
     }
     offs[kRankBuckets - 1 - t] = sh[t] - mine;
+    // (tail hand-off, KParams::dyn_ctr: the launch that follows has offs[0] unfinished instances to solve -- everything above bucket 0)
+    if (dyn_ctr && t == kRankBuckets - 1) dyn_ctr[0] = 0, dyn_ctr[1] = 0, dyn_ctr[2] = sh[t] - mine;
 }
 template <typename T>
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const T* resume, const int* status, int B, int* offs, int* order, int key)
@@ -744,6 +752,23 @@ SolveFn<T> pick_solve_spec(int lps, bool glb, int rs = 0, int only = 1)
     return lps == 3 ? solve_spec_kernel<T, 3, false> : lps == 2 ? solve_spec_kernel<T, 2, false> : solve_spec_kernel<T, 1, false>;
 }
 
+// The tail member of the fp32 register-table kernels (nmpc_config.tail_latency): the latency kernel with the throughput
+// kernels' evaluation; nullptr where there is none.
+template <typename T>
+SolveFn<T> pick_solve_tail(int lps, bool glb, int rs, int only)
+{
+    if constexpr (sizeof(T) == 4) {
+        if (lps != 3 || glb) return nullptr;
+        if (rs == kRegSlotsSmall)
+            return only == 2 ? solve_spec_kernel<T, 3, false, kRegSlotsSmall, 2, false> : solve_spec_kernel<T, 3, false, kRegSlotsSmall, 1, false>;
+        if (rs == kRegSlotsMid)
+            return only == 2 ? solve_spec_kernel<T, 3, false, kRegSlotsMid, 2, false> : solve_spec_kernel<T, 3, false, kRegSlotsMid, 1, false>;
+        if (rs == kRegSlotsLarge)
+            return only == 2 ? solve_spec_kernel<T, 3, false, kRegSlotsLarge, 2, false> : solve_spec_kernel<T, 3, false, kRegSlotsLarge, 1, false>;
+    }
+    return nullptr;
+}
+
 // (global table: `only` = 1 the compressed-table member of the pair, 2 the general one)
 template <typename T>
 SolveFn<T> pick_solve_coop(int lps, bool glb, int only = 2)
@@ -950,17 +975,35 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
 
 // one launch of the planned kernel over `grid` workgroups
 template <typename T>
-int launch_plan(nmpc_handle_s* h, const Plan<T>& pl, const nmpc::KParams<T>& k, int grid)
+int launch_plan(nmpc_handle_s* h, const Plan<T>& pl, const nmpc::KParams<T>& k, int grid, hipStream_t stream = nullptr, bool own = true)
 {
+    if (own) stream = h->stream;
+    if (grid <= 0) return 0;
     if (!pl.fn2 || k.axis_mode != 0) { // (axis_mode 0 = the general path only: the axis-only kernel of a pair has nothing to do)
-        hipLaunchKernelGGL(pl.fn, dim3(grid), dim3(pl.threads), pl.lds_bytes, h->stream, k);
+        hipLaunchKernelGGL(pl.fn, dim3(grid), dim3(pl.threads), pl.lds_bytes, stream, k);
         HIP_TRY(hipGetLastError());
     }
     if (pl.fn2 && k.axis_mode != 1) {
-        hipLaunchKernelGGL(pl.fn2, dim3(grid), dim3(pl.threads), pl.lds_bytes, h->stream, k);
+        hipLaunchKernelGGL(pl.fn2, dim3(grid), dim3(pl.threads), pl.lds_bytes, stream, k);
         HIP_TRY(hipGetLastError());
     }
     return 0;
+}
+
+// the tail member that goes with a throughput plan (fn == nullptr: none -- other kernel family, fp64, LDS / global table)
+template <typename T>
+Plan<T> plan_tail(nmpc_handle_s* h, const Plan<T>& pl, const Layout& L, int waves)
+{
+    Plan<T> t;
+    if (pl.mode != 0 || pl.uses_ws || !h->spec_ok[sizeof(T) == 4 ? 0 : 1]) return t;
+    t.fn = pick_solve_tail<T>(h->lps, L.glb, L.rs, 1);
+    if (!t.fn) return t;
+    t.fn2 = pl.has_axis ? pick_solve_tail<T>(h->lps, L.glb, L.rs, 2) : nullptr;
+    t.has_axis = pl.has_axis;
+    t.threads = 64 * waves;
+    t.lds_bytes = (size_t)(L.lds_xch + spec_xch_elems(waves)) * sizeof(T);
+    t.mode = 1;
+    return t;
 }
 
 // How the axis-aligned variant takes part in a call over B instances at P (device): sets k.axis_mode to 0 (general only),
@@ -1035,27 +1078,67 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
             ++n_stage;
         }
     h->last_staged = n_stage == 0 ? 0 : n_stage == 1 ? stage_cap[0] : 100 * stage_cap[0] + stage_cap[1];
-    if (n_stage == 0) return launch_plan<T>(h, pl, k, B);
+    // Tail hand-off (nmpc_config.tail_latency; round 6). A launch of the throughput kernel ends with
+    // whatever long solves are still running -- one wavefront each, alone on its SIMD -- while the rest of the chip idles: on
+    // batches with a skewed distribution of solve lengths the launch IS its longest instance
+    // (profiles/r05_cfg2_passing_kernel_timeline.txt). The latency family's TAIL member (solve_spec_kernel<.., FLAT = false>:
+    // speculative line search over four wavefronts, the throughput kernels' own evaluation) computes the throughput kernels'
+    // bits and solves a long instance ~1.8x faster on an idle chip (tools/exp_tail_solo.py). So the LAST throughput launch
+    // of a solve parks whatever is still running once it is in its drain phase -- every workgroup dispatched, at most
+    // `park` instances left (KParams::dyn_ctr) -- at the instance's next outer-iteration boundary, and one more launch
+    // -- the tail member over the parked instances, found by the same ranking kernels -- finishes them. Who solves which
+    // part of an instance depends on timing; the results do not (tests/test_gpu_tail.py). (Running the two families side by
+    // side on two streams does not work: with tens of thousands of one-wavefront workgroups pending, a four-wavefront
+    // workgroup never finds its four slots on one CU and runs after the throughput launch -- profiles/r06_ab_tail_handoff.jsonl.)
+    h->last_tail = 0;
+    int park = h->cfg.tail_latency;
+    const int tail_waves = kSpecWaves;
+    if (park == 0) park = std::max(32, h->n_simd / 4);      // automatic: one tail workgroup per CU (its four wavefronts alone on their SIMDs)
+    const bool big = B >= 4 * (pl.resident ? pl.resident : resident);
+    const Plan<T> tail = (park > 0 && allow_staging && k.status && pl.stageable && (n_stage > 0 || (k.order && big)) && B >= 8 * park)
+                             ? plan_tail<T>(h, pl, L, tail_waves) : Plan<T>();
+    if (n_stage == 0 && !tail.fn) return launch_plan<T>(h, pl, k, B);
 
     if (int rc = h->dresume.reserve((size_t)B * nmpc::kResumeStride * sizeof(T))) return rc;
     if (int rc = h->dorder2.reserve((size_t)B * sizeof(int))) return rc;
     k.resume = static_cast<T*>(h->dresume.p);
     int* hist = static_cast<int*>(h->dhist.p);
     int* offs = hist + kRankBuckets;
+    int* dctr = offs + kRankBuckets;             // (KParams::dyn_ctr: three counters behind the bucket tables)
     int* order2 = static_cast<int*>(h->dorder2.p);
     const int nb = (B + 255) / 256;
+    auto rank = [&](int key, bool publish) {
+        hipLaunchKernelGGL(rank_hist_kernel<T>, dim3(nb), dim3(256), 0, h->stream, k.resume, k.status, B, hist, key);
+        hipLaunchKernelGGL(rank_scan_kernel, dim3(1), dim3(kRankBuckets), 0, h->stream, hist, offs, publish ? dctr : nullptr);
+        hipLaunchKernelGGL(rank_scatter_kernel<T>, dim3(nb), dim3(256), 0, h->stream, k.resume, k.status, B, offs, order2, key);
+        return hipGetLastError();
+    };
     for (int i = 0; i <= n_stage; ++i) {
         nmpc::KParams<T> ki = k;
         ki.stage_in = i > 0;
         ki.stage_outer_cap = i < n_stage ? stage_cap[i] : 0;
         if (i > 0) ki.order = order2;
+        if (i == n_stage && tail.fn) { // the last throughput launch parks its drain phase (the counters: set by the ranking before it)
+            if (n_stage == 0) {        // (one launch under the caller's order: all B instances are to be solved)
+                hipLaunchKernelGGL(dyn_init_kernel, dim3(1), dim3(1), 0, h->stream, dctr, B);
+                HIP_TRY(hipGetLastError());
+            }
+            ki.dyn_ctr = dctr;
+            ki.dyn_park = park;
+        }
         if (int rc = launch_plan<T>(h, pl, ki, B)) return rc;
         if (i == n_stage) break;
-        hipLaunchKernelGGL(rank_hist_kernel<T>, dim3(nb), dim3(256), 0, h->stream, k.resume, k.status, B, hist, stage_key[i]);
-        hipLaunchKernelGGL(rank_scan_kernel, dim3(1), dim3(kRankBuckets), 0, h->stream, hist, offs);
-        hipLaunchKernelGGL(rank_scatter_kernel<T>, dim3(nb), dim3(256), 0, h->stream, k.resume, k.status, B, offs, order2,
-                           stage_key[i]);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(rank(stage_key[i], i + 1 == n_stage && tail.fn != nullptr));
+    }
+    if (tail.fn) {
+        // the parked instances (status -1) first in order2 -- at most `park` of them by construction -- and the tail member over them
+        HIP_TRY(rank(0, false));
+        nmpc::KParams<T> kt = k;
+        kt.stage_in = 1;
+        kt.stage_outer_cap = 0;
+        kt.order = order2;
+        if (int rc = launch_plan<T>(h, tail, kt, std::min(B, park))) return rc;
+        h->last_tail = park;
     }
     return 0;
 }
@@ -1206,9 +1289,9 @@ int polish_batch(nmpc_handle_s* h, const nmpc::KParams<T>& k, int B, bool y_user
     q.status = static_cast<int*>(h->pstatus.p);
     q.iters = static_cast<int*>(h->piters.p);
     q.info = static_cast<double*>(h->pinfo.p);
-    const int keep_mode = h->last_mode, keep_axis = h->last_axis, keep_staged = h->last_staged;
+    const int keep_mode = h->last_mode, keep_axis = h->last_axis, keep_staged = h->last_staged, keep_tail = h->last_tail;
     rc = run_solve<double>(h, q, ns, false);
-    h->last_mode = keep_mode, h->last_axis = keep_axis, h->last_staged = keep_staged;
+    h->last_mode = keep_mode, h->last_axis = keep_axis, h->last_staged = keep_staged, h->last_tail = keep_tail;
     if (rc) return rc;
     hipLaunchKernelGGL(polish_scatter_kernel<T>, dim3(ns), dim3(128), 0, h->stream, sel, (const double*)q.U, (const double*)q.y,
                        (const double*)q.cost, (const int*)q.status, (const int*)q.iters, (const double*)q.info, n2, k.U, k.y,
@@ -1579,9 +1662,12 @@ int set_lds_limit(nmpc_handle_s* h)
     if (spec_bytes > kLdsLimit) {
         h->spec_ok[sizeof(T) == 4 ? 0 : 1] = false; // no room for the exchange area: latency mode unavailable
     } else if (spec_bytes > 48 * 1024) {
-        for (int only = 1; only <= 2; ++only)
+        for (int only = 1; only <= 2; ++only) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_solve_spec<T>(h->lps, L.glb, L.rs, only)),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)spec_bytes));
+            if (auto* tf = pick_solve_tail<T>(h->lps, L.glb, L.rs, only))
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)spec_bytes));
+        }
     }
     return 0;
 }
@@ -1645,7 +1731,7 @@ int nmpc_default_config(nmpc_config* c)
     c->polish_tolerance = 1e-6;
     c->polish_delta_tolerance = 1e-5;
     c->max_evaluations = 0;
-    c->reserved0 = 0;
+    c->tail_latency = 0;
     return 0;
 }
 
@@ -1699,6 +1785,7 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
     if (!(cfg->max_solver_time_us >= 0))
         return fail(NMPC_ERR_INVALID_ARGUMENT, "max_solver_time_us < 0");
     if (cfg->max_evaluations < 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "max_evaluations = %d < 0", cfg->max_evaluations);
+    if (cfg->tail_latency < -1) return fail(NMPC_ERR_INVALID_ARGUMENT, "tail_latency = %d < -1", cfg->tail_latency);
     if (cfg->staged_evals < -1) return fail(NMPC_ERR_INVALID_ARGUMENT, "staged_evals = %d < -1", cfg->staged_evals);
     if (cfg->axis_aligned < -1 || cfg->axis_aligned > 1)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "axis_aligned = %d (0 automatic, 1 promised, -1 never)", cfg->axis_aligned);
@@ -1751,8 +1838,8 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
     }
     int rc = h->dflag.reserve(4 * sizeof(int));
     if (rc == 0 && hipMemset(h->dflag.p, 0, 4 * sizeof(int)) != hipSuccess) rc = fail(NMPC_ERR_HIP, "hipMemset failed");
-    if (rc == 0) rc = h->dhist.reserve(2 * kRankBuckets * sizeof(int)); // (bucket counters of the resumable solve, kept zeroed)
-    if (rc == 0 && hipMemset(h->dhist.p, 0, 2 * kRankBuckets * sizeof(int)) != hipSuccess) rc = fail(NMPC_ERR_HIP, "hipMemset failed");
+    if (rc == 0) rc = h->dhist.reserve((2 * kRankBuckets + 4) * sizeof(int)); // (bucket counters of the resumable solve, kept zeroed; + the tail hand-off's three)
+    if (rc == 0 && hipMemset(h->dhist.p, 0, (2 * kRankBuckets + 4) * sizeof(int)) != hipSuccess) rc = fail(NMPC_ERR_HIP, "hipMemset failed");
     if (rc == 0) rc = set_lds_limit<float>(h);
     if (rc == 0) rc = set_lds_limit<double>(h);
     if (rc) {
@@ -1914,6 +2001,7 @@ int nmpc_last_launch_info(nmpc_handle h, int32_t out[8])
     out[1] = h->last_axis;
     out[2] = h->last_staged;
     out[3] = h->last_polish_selected;
+    out[4] = h->last_tail;
     return 0;
 }
 

@@ -34,7 +34,14 @@ namespace nmpc {
 
 enum SpecPhase : int { SP_INIT_A, SP_INIT_B, SP_LIP, SP_SPEC0, SP_NOLS, SP_LSN, SP_OUTER };
 
-template <typename T, int LPS, bool GLB, int RS = 0, bool AXIS = false>
+// FLAT: how the obstacle passes of an evaluation are written. true (the latency family proper): the pair form WITHOUT its
+// early-outs -- straight-line code whose LDS reads and DPP chains overlap, what a lone instance wants. false (round 6, the
+// TAIL member): the throughput kernels' gated form, i.e. the very evaluation solve_instance() runs. That form is the ONLY
+// numerical difference between the two families: with it this kernel returns the throughput kernels' bits (every row of
+// profiles/r06_family_bits.txt, fp32 and fp64), which is what lets a launch of the throughput kernel hand its longest
+// instances -- parked in its drain phase -- to the speculative line search without an instance's result depending on what
+// else is in its batch (nmpc_config.tail_latency; nmpc_capi.hip, run_solve).
+template <typename T, int LPS, bool GLB, int RS = 0, bool AXIS = false, bool FLAT = true>
 __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const int inst, T* lds)
 {
     // W is a run-time value (workgroup size / 64, at most kMaxSpecWaves) so that every choice of W executes the very
@@ -281,13 +288,10 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         }
         const T e_icd = ec == c ? inv_cdiv : T(1);
         if (do_eval) {
-#ifndef NMPC_SPEC_FLAT
-#define NMPC_SPEC_FLAT 1
-#endif
             if (want_grad)
-                I.template eval<true, NMPC_SPEC_FLAT != 0>(ev, ew, ec, e_icd, yv, yw, r_psi, r_f2, r_gv, r_gw);
+                I.template eval<true, FLAT>(ev, ew, ec, e_icd, yv, yw, r_psi, r_f2, r_gv, r_gw);
             else
-                I.template eval<false, NMPC_SPEC_FLAT != 0>(ev, ew, ec, e_icd, yv, yw, r_psi, r_f2, r_gv, r_gw);
+                I.template eval<false, FLAT>(ev, ew, ec, e_icd, yv, yw, r_psi, r_f2, r_gv, r_gw);
         }
         // The forward-backward envelope of a line-search candidate -- the left-hand side of its acceptance test -- by the
         // wavefront that evaluated it (round 5): psi - gamma/2 ||grad||^2 + ||gradient_step - Proj_U(gradient_step)||^2 / (2 gamma)

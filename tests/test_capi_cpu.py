@@ -36,7 +36,7 @@ def test_config_struct_matches_header_defaults():
     assert cfg.coop_waves == 0 and cfg.axis_aligned == 0 and cfg.reg_table == 0 and cfg.staged == 0
     assert cfg.polish == 0 and cfg.polish_max_outer_iterations == 4 and cfg.polish_max_inner_iterations == 150
     assert cfg.polish_tolerance == 1e-6 and cfg.polish_delta_tolerance == 1e-5 and cfg.staged_evals == 0
-    assert cfg.max_evaluations == 0 and cfg.reserved0 == 0
+    assert cfg.max_evaluations == 0 and cfg.tail_latency == 0
     # struct size and a late field's offset: ctypes mirror vs the C compiler on include/nmpc_hip.h (catches field drift)
     import subprocess, tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

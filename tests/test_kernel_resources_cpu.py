@@ -54,18 +54,27 @@ def test_register_budgets_of_the_kernel_variants(resources):
     for only in (1, 2):
         assert resources[f"solve_kernel<float, 3, false, 14, {only}>"]["vgpr"] <= 256
         assert resources[f"solve_kernel<float, 3, false, 4, {only}>"]["vgpr"] <= 168
-        assert resources[f"solve_spec_kernel<float, 3, false, 4, {only}>"]["vgpr"] <= 168
+        assert resources[f"solve_spec_kernel<float, 3, false, 4, {only}, true>"]["vgpr"] <= 168
         assert resources[f"solve_kernel<float, 3, false, 6, {only}>"]["vgpr"] <= 168
-        assert resources[f"solve_spec_kernel<float, 3, false, 6, {only}>"]["vgpr"] <= 168
+        assert resources[f"solve_spec_kernel<float, 3, false, 6, {only}, true>"]["vgpr"] <= 168
+        # (round 6: the TAIL members -- the latency kernel with the throughput kernels' gated evaluation -- keep the budgets)
+        assert resources[f"solve_spec_kernel<float, 3, false, 4, {only}, false>"]["vgpr"] <= 168
+        assert resources[f"solve_spec_kernel<float, 3, false, 6, {only}, false>"]["vgpr"] <= 168
+        assert resources[f"solve_spec_kernel<float, 3, false, 14, {only}, false>"]["vgpr"] <= 256
     assert resources["solve_kernel<float, 3, false, 0, 0>"]["vgpr"] <= 168
-    for name, r in _sel(resources, r"^solve_spec_kernel<float, \d, (true|false), 0, 0>").items():
+    for name, r in _sel(resources, r"^solve_spec_kernel<float, \d, (true|false), 0, 0, true>").items():
         assert r["vgpr"] <= 168 and r["vgpr_spill"] == 0, (name, r)
 
 
 def test_fp32_latency_and_cooperative_kernels_spill_little(resources):
     for name, r in _sel(resources, r"^solve_spec_kernel<float").items():
-        general = re.search(r"<float, 3, false, (4|14), 2>", name) is not None
-        axis = re.search(r"<float, 3, false, (4|14), 1>", name) is not None
+        if name.endswith(", false>"):
+            # TAIL members (round 6): a few instances per launch run on them; the gated evaluation next to the latency kernel's
+            # solver state costs 3-20 more spilled VGPRs than the flat form (42 in the general 6-slot member)
+            assert r["sgpr_spill"] <= 56 and r["vgpr_spill"] <= 44 and r["scratch"] <= 192, (name, r)
+            continue
+        general = re.search(r"<float, 3, false, (4|14), 2, true>", name) is not None
+        axis = re.search(r"<float, 3, false, (4|14), 1, true>", name) is not None
         # (round 4: the solver's integer state stays in scalar registers all the way round the loop -- no v_readfirstlane per
         #  variable and evaluation any more -- and the master / worker split added the command addresses: ~30 SGPRs take
         #  the v_writelane / v_readlane route, outside the evaluation; measured +6.5 % and +5.8 % on configs[1] all the same)
@@ -74,7 +83,7 @@ def test_fp32_latency_and_cooperative_kernels_spill_little(resources):
         #  scalar load; with the candidates' FBE formed by the wavefront that evaluated them +1.8 % on configs[1])
         assert r["sgpr_spill"] <= 52, (name, r)
         # (general path of the register-table variants: up to 23 VGPRs in scratch; the axis-aligned members: 0 / 9 dwords)
-        mid = re.search(r"<float, 3, false, 6, (1|2)>", name)       # (6-slot kernels: 16 / 32 VGPRs in scratch, see above)
+        mid = re.search(r"<float, 3, false, 6, (1|2), true>", name)       # (6-slot kernels: 16 / 32 VGPRs in scratch, see above)
         # (round 6: an LDS-table member may carry the same unused 9-dword frame object as the 14-slot axis member: private
         #  segment 36 B with NO spilled vector register and NO scratch instruction in its code -- checked on the disassembly)
         phantom = r["scratch"] == 36 and r["vgpr_spill"] == 0 and r["scratch_instr"] == 0

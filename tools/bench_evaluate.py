@@ -8,7 +8,7 @@ The comparison figure is the reference's own way of doing this: one scenario aft
    env: FAMILY=reference (default: the reference's scenario_0..2 on its warehouse map, HUMAN_STAGGER 0.5,
         scenarios.make_reference_scenarios) | corridor (round 5's builder-designed family);
         BUDGET=yaml (nmpc_config.max_evaluations from mpc_fast.yaml's max_solver_time = 0.1 s, solver.evaluation_budget) |
-        <count> | 0 (default: iteration caps only); DISPATCH=index."""
+        <count> | 0 (default: iteration caps only); DISPATCH=index; TAIL=<nmpc_config.tail_latency> (-1 = no tail hand-off)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -33,6 +33,7 @@ cfg.max_active_dynobs = n_ped * n_hyp
 budget = os.environ.get("BUDGET", "0")
 cfg.max_evaluations = (evaluation_budget(100_000, cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs) if budget == "yaml"
                        else int(budget))
+cfg.tail_latency = int(os.environ.get("TAIL", "0"))
 warm = make(64, seed=14, n_ped=n_ped)
 warm.pop("scenario_index", None)
 BatchEvaluator(cfg, dtype=dtype, n_hyp=n_hyp, **warm).run(max_steps=3)  # warm-up
@@ -67,7 +68,7 @@ if sidx is not None:
 print(json.dumps({
     "metric": "scenario time-steps/sec (f3, batched closed-loop evaluation)", "value": scen_steps / el, "unit": "steps/s",
     "n_gpus": 1, "dtype": "f32" if dtype == np.float32 else "f64", "wall_s": el,
-    "family": family, "max_evaluations": int(cfg.max_evaluations), "human_stagger": stagger,
+    "family": family, "max_evaluations": int(cfg.max_evaluations), "tail_latency": int(cfg.tail_latency), "human_stagger": stagger,
     "config": {"workload": f"B={B} scenarios x <= {max_steps} steps, mpc_fast.yaml, " + ("scenario_0..2 on the 55-polygon warehouse map" if family == "reference" else "14 map boxes") + f", {n_ped} pedestrians x {n_hyp} "
                            f"hypotheses (Ndynobs = {cfg.Ndynobs}; " + ("constant-velocity rows" if n_hyp == 1 else "fan around the constant-velocity prediction") + ")"},
     "lockstep_steps": len(res.solve_ms), "scenario_steps": scen_steps,

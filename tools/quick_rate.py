@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: solves/s of one BASELINE workload from the kernel time alone (no CPU baseline, no accuracy section).
    usage: quick_rate.py [cfg1|cfg2|cfg4] [B] [launches]   env: LW (latency_waves), COOP (coop_waves), RT (reg_table), DT=f64,
-   AX (axis_aligned), STAGED (staged), STAGED2 (staged_evals), POLISH=1, FAMILY, ORDER=lpt"""
+   AX (axis_aligned), STAGED (staged), STAGED2 (staged_evals), POLISH=1, FAMILY, ORDER=lpt, TAIL (tail_latency), BUDGET (max_evaluations)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,7 +19,7 @@ cfg = nm.default_config_struct()
 cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs = L.N, L.Nother, L.Nstc, L.Ndyn
 cfg.max_active_dynobs = spec["n_ped"] * spec["n_hyp"]
 cfg.latency_waves = int(os.environ.get("LW", "0")); cfg.coop_waves = int(os.environ.get("COOP", "0")); cfg.reg_table = int(os.environ.get("RT", "0"))
-cfg.axis_aligned = int(os.environ.get("AX", "0")); cfg.staged = int(os.environ.get("STAGED", "0")); cfg.staged_evals = int(os.environ.get("STAGED2", "0")); cfg.polish = int(os.environ.get("POLISH", "0"))
+cfg.axis_aligned = int(os.environ.get("AX", "0")); cfg.staged = int(os.environ.get("STAGED", "0")); cfg.staged_evals = int(os.environ.get("STAGED2", "0")); cfg.polish = int(os.environ.get("POLISH", "0")); cfg.tail_latency = int(os.environ.get("TAIL", "0")); cfg.max_evaluations = int(os.environ.get("BUDGET", "0"))
 h = nm.Handle(cfg)
 P = np.ascontiguousarray(P, dtype=dt)
 U = np.empty((B, 2 * L.N), dt); it = np.empty((B, 2), np.int32); st = np.empty(B, np.int32)
