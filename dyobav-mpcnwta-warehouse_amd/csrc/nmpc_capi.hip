@@ -81,7 +81,7 @@ struct Layout {
     int np, off_rs, off_rv, off_c0, off_c, off_os, off_od, off_qstc, off_qdyn;
     int lds_alpha, lds_poly, lds_seg, lds_seginv, lds_fl0, lds_fl, lds_iflag, lds_hist, lds_rho, lds_total;
     int lds_xch, lds_total_spec; // latency mode: exchange area + the other wavefronts' parking areas behind lds_total
-    int lds_park;
+    int lds_park, lds_deepsc;
     int coop_lanes, lds_t0c; // cooperative kernels: lanes per plane of the exchange area; t = 0 rows of the compressed global table
     int lds_xch_coop, lds_total_coop; // cooperative mode: two shared parking areas, then the partial-sum exchange area
     int lds_left, lds_left_alpha;     // LDS table of the rows beyond the register-resident ones (cooperative register kernel)
@@ -183,7 +183,8 @@ Layout make_layout(const nmpc_config& c, size_t elem_size, bool coop_rs = false,
     L.lds_rho = L.lds_hist + 4 * nmpc::kMem * nmpc::lbfgs_slot_stride(N); // L-BFGS ring: kMem slots x (N | 1) x (s_v, s_w, y_v, y_w)
     L.lds_park = L.lds_rho + round4(2 * nmpc::kMem);   // rho[kMem], alpha[kMem]; then the parking area(s) (16-B aligned)
     const int park_one = nmpc::kParkQuads * 4 * 64;    // elements per wavefront
-    L.lds_total = L.lds_park + park_one;
+    L.lds_deepsc = L.lds_park + park_one;              // scalar block of a deep park (tail hand-off), throughput kernels only
+    L.lds_total = L.lds_deepsc + nmpc::kDeepScalars;
     // latency kernel: the exchange area of W wavefronts (nmpc_spec.h) in place of the parking area (its solver vectors stay
     // in registers): W result rows of 64 x 2 gradient entries + psi (padded to 132), the master's command area of
     // 2 x 64 x W + 4 scalars
@@ -245,6 +246,7 @@ struct nmpc_handle_s {
     DevBuf dflag;    // [0]: epoch of the last call whose batch had an ellipse with angle != 0 (KParams::axis_flag)
     int axis_epoch = 0;
     DevBuf dresume, dorder2, dhist; // resumable solve: parked states, ranked order of the second launch, bucket counters
+    DevBuf ddeep;                   // tail hand-off: solver states parked inside an inner solve (KParams::deep)
     // polish: compact fp64 copies of the selected instances and their results
     DevBuf psel, pP, pU0, pY, pC, pU, pcost, pstatus, piters, pinfo;
     std::vector<int32_t> host_status, host_sel;
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256) void rank_hist_kernel(const T* resume, const i
     else if (q == 0 && (int)(threadIdx.x & 63) == __ffsll((long long)m0) - 1) atomicAdd(&hist[0], __popcll(m0));
 }
 // (tail hand-off under a caller's dispatch order, no ranking before the launch: all B instances are to be solved)
-__global__ void dyn_init_kernel(int* dyn_ctr, int total) { dyn_ctr[0] = 0, dyn_ctr[1] = 0, dyn_ctr[2] = total; }
+__global__ void dyn_init_kernel(int* dyn_ctr, int total) { dyn_ctr[0] = 0, dyn_ctr[1] = 0, dyn_ctr[2] = total, dyn_ctr[3] = 0; }
 // offs[q] = number of instances in buckets above q (one workgroup of kRankBuckets threads; reversed inclusive scan)
 // (the counters are left zeroed for the next ranking: no memset between launches)
 __global__ __launch_bounds__(kRankBuckets) void rank_scan_kernel(int* hist, int* offs, int* dyn_ctr)
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(kRankBuckets) void rank_scan_kernel(int* hist, int*
     }
     offs[kRankBuckets - 1 - t] = sh[t] - mine;
     // (tail hand-off, KParams::dyn_ctr: the launch that follows has offs[0] unfinished instances to solve -- everything above bucket 0)
-    if (dyn_ctr && t == kRankBuckets - 1) dyn_ctr[0] = 0, dyn_ctr[1] = 0, dyn_ctr[2] = sh[t] - mine;
+    if (dyn_ctr && t == kRankBuckets - 1) dyn_ctr[0] = 0, dyn_ctr[1] = 0, dyn_ctr[2] = sh[t] - mine, dyn_ctr[3] = 0;
 }
 template <typename T>
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const T* resume, const int* status, int B, int* offs, int* order, int key)
@@ -613,6 +615,7 @@ void fill_layout(nmpc::KParams<T>& k, const Layout& L)
     k.lds_total = L.lds_total;
     k.lds_xch = L.lds_xch;
     k.lds_park = L.lds_park;
+    k.lds_deepsc = L.lds_deepsc;
     k.coop_lanes = L.coop_lanes;
     k.lds_t0c = L.lds_t0c;
     k.lds_left = L.lds_left;
@@ -1098,13 +1101,17 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
     const Plan<T> tail = (park > 0 && allow_staging && k.status && pl.stageable && (n_stage > 0 || (k.order && big)) && B >= 8 * park)
                              ? plan_tail<T>(h, pl, L, tail_waves) : Plan<T>();
     if (n_stage == 0 && !tail.fn) return launch_plan<T>(h, pl, k, B);
+    if (tail.fn) {
+        if (int rc = h->ddeep.reserve((size_t)park * nmpc::deep_park_stride(h->cfg.N_hor) * sizeof(T))) return rc;
+        k.deep = static_cast<T*>(h->ddeep.p);   // (read by the tail launch; handed to the LAST throughput launch only)
+    }
 
     if (int rc = h->dresume.reserve((size_t)B * nmpc::kResumeStride * sizeof(T))) return rc;
     if (int rc = h->dorder2.reserve((size_t)B * sizeof(int))) return rc;
     k.resume = static_cast<T*>(h->dresume.p);
     int* hist = static_cast<int*>(h->dhist.p);
     int* offs = hist + kRankBuckets;
-    int* dctr = offs + kRankBuckets;             // (KParams::dyn_ctr: three counters behind the bucket tables)
+    int* dctr = offs + kRankBuckets;             // (KParams::dyn_ctr: four counters behind the bucket tables)
     int* order2 = static_cast<int*>(h->dorder2.p);
     const int nb = (B + 255) / 256;
     auto rank = [&](int key, bool publish) {
@@ -1115,6 +1122,7 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
     };
     for (int i = 0; i <= n_stage; ++i) {
         nmpc::KParams<T> ki = k;
+        ki.deep = nullptr;
         ki.stage_in = i > 0;
         ki.stage_outer_cap = i < n_stage ? stage_cap[i] : 0;
         if (i > 0) ki.order = order2;
@@ -1125,6 +1133,8 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
             }
             ki.dyn_ctr = dctr;
             ki.dyn_park = park;
+            ki.deep = k.deep;       // (parking inside an inner solve: the slots reserved below)
+            ki.deep_slots = park;
         }
         if (int rc = launch_plan<T>(h, pl, ki, B)) return rc;
         if (i == n_stage) break;
@@ -1857,7 +1867,7 @@ int nmpc_destroy(nmpc_handle h)
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (DevBuf* b : {&h->dP, &h->dU, &h->dcost, &h->dstatus, &h->diters, &h->du0, &h->dy, &h->dc0, &h->dinfo,
                       &h->dY2, &h->dC2, &h->dpsi, &h->dgrad, &h->df2, &h->dws, &h->dorder, &h->dflag, &h->dresume,
-                      &h->dorder2, &h->dhist, &h->psel, &h->pP, &h->pU0, &h->pY, &h->pC, &h->pU, &h->pcost, &h->pstatus,
+                      &h->dorder2, &h->dhist, &h->ddeep, &h->psel, &h->pP, &h->pU0, &h->pY, &h->pC, &h->pU, &h->pcost, &h->pstatus,
                       &h->piters, &h->pinfo})
         b->release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);

@@ -32,7 +32,7 @@
 
 namespace nmpc {
 
-enum SpecPhase : int { SP_INIT_A, SP_INIT_B, SP_LIP, SP_SPEC0, SP_NOLS, SP_LSN, SP_OUTER };
+enum SpecPhase : int { SP_INIT_A, SP_INIT_B, SP_LIP, SP_SPEC0, SP_NOLS, SP_LSN, SP_OUTER, SP_RESUME };
 
 // FLAT: how the obstacle passes of an evaluation are written. true (the latency family proper): the pair form WITHOUT its
 // early-outs -- straight-line code whose LDS reads and DPP chains overlap, what a lone instance wants. false (round 6, the
@@ -135,6 +135,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     const long long t_start = time_budget > 0 ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
     int t_now = 0;
     int cont_time = 1;
+    int deep_slot = 0; // > 0: the instance was parked inside an inner solve (KParams::deep)
 
     // exchange area: 2 buffers x W wavefronts x (64 lanes x (g_v, g_w) + psi, padded to 4). Per lane, not per step:
     // the LPS lanes of a step hold copies of the step's scalars that may differ in the last bit (each lane's
@@ -195,6 +196,36 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
         rounds = __builtin_amdgcn_readfirstlane((int)sc[9]);
         yv = tclamp(yv, T(-1e12), T(1e12));
         yw = tclamp(yw, T(-1e12), T(1e12));
+        if constexpr (!FLAT) deep_slot = __builtin_amdgcn_readfirstlane((int)sc[10]); // (the tail member only: nothing else is handed deep parks)
+        if (deep_slot > 0) {
+            // parked INSIDE an inner solve by the throughput kernel (tail hand-off, KParams::deep): the whole solver state as it
+            // stood between two PANOC iterations; the loop below is entered at the head of the iteration that comes next
+            // (SP_RESUME). Every wavefront restores its registers; the ring in LDS belongs to the master.
+            const T* g = cold_args<T>()->deep + (size_t)(deep_slot - 1) * deep_park_stride(N);
+            const Quad<T>* pq = reinterpret_cast<const Quad<T>*>(g) + I.lane;   // park() layout: [quad][lane]
+            const Quad<T> q0 = pq[0 * 64], q1 = pq[1 * 64], q3 = pq[3 * 64], q4 = pq[4 * 64];
+            osv = q0.a, osw = q0.b, ogv = q0.c, ogw = q0.d;
+            sv = q1.c, sw = q1.d;
+            hv = q3.a, hw = q3.b;
+            uv = q4.a, uw = q4.b, gv = q4.c, gw = q4.d;
+            g += kParkQuads * 64 * 4;
+            const int nr = deep_ring_elems(N);
+            if (role == 0) {
+                T* ring = reinterpret_cast<T*>(hist);
+                for (int i = I.lane; i < nr; i += 64) ring[i] = g[i];
+            }
+            g += nr;
+            yv = g[I.lane], yw = g[64 + I.lane], rho.v = g[128 + I.lane];
+            const T* ds = g + 192;
+            gamma = ds[kDeepScGamma], inv_gamma = ds[kDeepScInvGamma], L = ds[kDeepScL], cost_value = ds[kDeepScCost], fbe_cur = ds[kDeepScFbe];
+            akkt_tol = ds[kDeepScAkkt], c = ds[kDeepScC], lb_gamma = ds[kDeepScLbGamma], dyn = ds[kDeepScDyn], f2n = ds[kDeepScF2n];
+            auto rd = [&](int j) { return __builtin_amdgcn_readfirstlane((int)ds[j]); };
+            iteration = rd(kDeepScIteration), num_iter = rd(kDeepScNumIter), cont = rd(kDeepScCont), cont_time = rd(kDeepScContTime);
+            fbe_valid = rd(kDeepScFbeValid), lb_active = rd(kDeepScLbActive), lb_head = rd(kDeepScLbHead), lb_first = rd(kDeepScLbFirst);
+            alm_iter = rd(kDeepScAlmIter), inner_total = rd(kDeepScInnerTotal), outer = rd(kDeepScOuter), alg_grad = rd(kDeepScNGrad);
+            rounds = 0;
+            evals_left = evals_budget() - rd(kDeepScNPsi);
+        }
     }
     // The solver options the master consults in EVERY iteration, read once (round 5): re-read from the kernel argument at the
     // point of use -- what the throughput kernels do to keep their scalar registers free -- each of them is a scalar load
@@ -202,10 +233,10 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
     // scalar register that ends up spilled to a VGPR lane costs one v_readlane instead.
     const T o_tol = kp.tol, o_sy_eps = kp.sy_eps, o_cbfgs_eps = kp.cbfgs_eps, o_cbfgs_alpha = kp.cbfgs_alpha;
     const int o_max_inner = kp.max_inner, o_akkt_form = kp.akkt_form;
-    int phase = SP_INIT_A;
+    int phase = deep_slot > 0 ? SP_RESUME : SP_INIT_A;
     T ev = uv, ew = uw, ec = c;
     T inv_cdiv = T(1) / (c > T(1) ? c : T(1));
-    int want_grad = 1, do_eval = 1, exchange = 0;
+    int want_grad = 1, do_eval = deep_slot > 0 ? 0 : 1, exchange = 0;
     T r_psi = 0, r_f2 = 0, r_gv = 0, r_gw = 0;
 
     // every wavefront evaluates the same request (results used locally, no exchange)
@@ -447,6 +478,8 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
             gw = r_gw;
             grad_step_half(uv, uw);
             step_done = true;
+        } else if (phase == SP_RESUME) {
+            step_head = true; // (deep resume: nothing was evaluated; the head of the next iteration on the restored state)
         } else if (phase == SP_LSN) {
             if (process_candidates(0)) {
                 step_done = true;
@@ -565,6 +598,7 @@ __device__ __forceinline__ void solve_instance_spec(const KParams<T>& kp, const 
                             sc[7] = T(evals_budget() - evals_left);
                             sc[8] = T(alg_grad);
                             sc[9] = T(rounds);
+                            sc[10] = T(0);
                             kc->status[ri] = -1;
                         }
                     }

@@ -69,9 +69,10 @@ def test_register_budgets_of_the_kernel_variants(resources):
 def test_fp32_latency_and_cooperative_kernels_spill_little(resources):
     for name, r in _sel(resources, r"^solve_spec_kernel<float").items():
         if name.endswith(", false>"):
-            # TAIL members (round 6): a few instances per launch run on them; the gated evaluation next to the latency kernel's
-            # solver state costs 3-20 more spilled VGPRs than the flat form (42 in the general 6-slot member)
-            assert r["sgpr_spill"] <= 56 and r["vgpr_spill"] <= 44 and r["scratch"] <= 192, (name, r)
+            # TAIL members (round 6): a few hundred instances per launch at most run on them; the gated evaluation and the
+            # deep-park reader next to the latency kernel's solver state cost 12-22 more spilled VGPRs than the flat form
+            # (axis-aligned members: 12 / 35 / 20 for 4 / 6 / 14 slots; 54 in the general 6-slot member)
+            assert r["sgpr_spill"] <= 56 and r["vgpr_spill"] <= 56 and r["scratch"] <= 200, (name, r)
             continue
         general = re.search(r"<float, 3, false, (4|14), 2, true>", name) is not None
         axis = re.search(r"<float, 3, false, (4|14), 1, true>", name) is not None
