@@ -213,8 +213,11 @@ def test_dispatch_order_changes_nothing_but_the_launch_time():
         h.set_dispatch_order(lpt[:100].argsort().astype(np.int32))          # an order for another batch size is ignored
         other_size = h.solve(P)
     for r in (shuffled, first, last, again, other_size):
-        for k in ("U", "cost", "status", "iters", "info"):
+        for k in ("U", "cost", "status", "iters"):
             assert np.array_equal(r[k], base[k]), k
+        # (info[6], info[7] are launch diagnostics -- exchange rounds / wavefronts per instance: under a dispatch order the tail
+        #  hand-off, nmpc_config.tail_latency, lets the latency family's tail member finish the drain phase of the launch)
+        assert np.array_equal(r["info"][:, :6], base["info"][:, :6]), "info"
     print(f"kernel ms: index order {t_base:.1f}, longest first {t_lpt:.1f}, shortest first {t_spt:.1f}")
     # (round 3 measured 156 -> 94 ms for 'longest first' on this family at B = 65 536; at this batch size the longest instance
     #  alone is most of the launch, so the margin asked for is a modest one)

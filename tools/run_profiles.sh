@@ -56,15 +56,20 @@ PY
 # 5. the next-row components
 python3 $R/tools/bench_assemble.py 2>/dev/null | tail -1 > $OUT/f1_assemble_bench.json
 python3 $R/tools/bench_hypotheses.py 2>/dev/null | tail -1 > $OUT/f2_hypotheses_bench.json
-python3 $R/tools/bench_evaluate.py 4096 60 f32 2>/dev/null | tail -1 > $OUT/f3_evaluate_b4096.json
-python3 $R/tools/bench_evaluate.py 1 60 f64 2>/dev/null | tail -1 > $OUT/f3_evaluate_b1_f64.json
-python3 $R/tools/bench_evaluate.py 65536 60 f32 2>/dev/null | tail -1 > $OUT/f3_evaluate_b65536.json
+# (FAMILY=corridor: round 5's builder-designed family, comparable with the r05 records)
+FAMILY=corridor python3 $R/tools/bench_evaluate.py 4096 60 f32 2>/dev/null | tail -1 > $OUT/f3_evaluate_b4096.json
+FAMILY=corridor python3 $R/tools/bench_evaluate.py 1 60 f64 2>/dev/null | tail -1 > $OUT/f3_evaluate_b1_f64.json
+FAMILY=corridor python3 $R/tools/bench_evaluate.py 65536 60 f32 2>/dev/null | tail -1 > $OUT/f3_evaluate_b65536.json
 # ... and at BASELINE configs[2]'s dimensions: 4 pedestrians x 10 hypotheses (Ndynobs = 40), the closed loop itself
-python3 $R/tools/bench_evaluate.py 65536 60 f32 4 10 2>/dev/null | tail -1 > $OUT/f3_evaluate_b65536_4x10.json
+FAMILY=corridor python3 $R/tools/bench_evaluate.py 65536 60 f32 4 10 2>/dev/null | tail -1 > $OUT/f3_evaluate_b65536_4x10.json
+# round 6: the REFERENCE's evaluation (scenario_0..2 on the warehouse map, 120-step cap), iteration caps only / with the
+# reference's time cap as the evaluation budget
+python3 $R/tools/bench_evaluate.py 65536 120 f32 4 10 2>/dev/null | tail -1 > $OUT/f3_evaluate_refscen_b65536_4x10.json
+BUDGET=yaml python3 $R/tools/bench_evaluate.py 65536 120 f32 4 10 2>/dev/null | tail -1 > $OUT/f3_evaluate_refscen_b65536_4x10_budget.json
 python3 $R/tools/solo_latency.py 2>/dev/null | grep "instance" > $OUT/solo_latency.txt
 python3 $R/tools/kernel_resources.py > $OUT/kernel_resources.txt 2>/dev/null
 python3 $R/tools/exp_three_per_wave.py > $OUT/exp_three_instances_per_wavefront.txt 2>/dev/null
-# 6. the closed-loop family of configs[2] under the kernel trace (same kernels as the headline, another distribution)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cl -- $B $LEAN --family closed_loop --steps 3 > $OUT/cfg2_closed_loop_bench_under_rocprof.json 2> $OUT/stats_cl.err
-find $OUT/stats_cl -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/cfg2_closed_loop_kernel_stats.csv
+# 6. the reference-scenario family of configs[2] under the kernel trace (same kernels as the headline, another distribution)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cl -- $B $LEAN --family refscen --steps 3 > $OUT/cfg2_refscen_bench_under_rocprof.json 2> $OUT/stats_cl.err
+find $OUT/stats_cl -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/cfg2_refscen_kernel_stats.csv
 ls $OUT
