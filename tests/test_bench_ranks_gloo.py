@@ -114,6 +114,20 @@ def test_bench_line_is_compact_with_every_optional_part():
     for k in ("cfg2_passing", "cfg2_closed_loop", "cfg1_passing"):
         assert acc[k]["tight_hip_orc"]["unexpl"] == 0 and acc[k]["tight_orc_twin"]["unexpl"] == 0 and acc[k]["audit"]["unexpl"] == 0
         assert acc[k]["tight_hip_orc"]["kkt_max_du"] < 1e-4            # both end points stationary -> inside the north star's bar
+    # ... and on round 6's record: the reference-scenario row with its budgeted twin, the evaluation-budget leg of the CPU baseline
+    d6 = json.load(open(os.path.join(ROOT, "profiles", "r06_cfg2_bench_detail.json")))
+    line6 = bench.compact_line(d6)
+    assert "\n" not in line6 and len(line6) < bench.LINE_TARGET_BYTES, len(line6)
+    rec6 = json.loads(line6)
+    assert {"cfg2_refscen_f32", "cfg2_refscen_f32_budget", "cfg2_closed_loop_f32", "cfg2_closed_loop_f32_budget", "cfg2_f32_budget"} <= set(rec6["secondary_solves_per_s"])
+    rs = rec6["reference_scenarios"]
+    assert rs["solves_per_s"] == rec6["secondary_solves_per_s"]["cfg2_refscen_f32"] and rs["capture_steps"] == [2, 14, 26]
+    assert rs["budget"]["max_evaluations"] == 2526 and 0 < rs["budget"]["out_of_time_frac"] < 1
+    assert rs["budget"]["solves_per_s"] == rec6["secondary_solves_per_s"]["cfg2_refscen_f32_budget"]
+    assert rec6["value"] < 1e5 < rs["solves_per_s"]                       # which side of the north star's 1e5 each falls on
+    assert rec6["cpu_baseline"]["evals_per_s_per_core"] > 0 and rec6["cpu_baseline"]["value_with_evaluation_budget"] > rec6["cpu_baseline"]["value"]
+    assert rec6["accuracy_summary"]["cfg2_refscen"]["audit"]["unexpl"] == 0 and rec6["accuracy_summary"]["cfg2_refscen"]["tight_hip_orc"]["unexpl"] == 0
+    assert rec6["config"]["tail_handed_off"] == 256
     detail["config"]["padding"] = "x" * 9000
     detail2 = dict(detail, config=dict(detail["config"], workload="y" * 9000))
     with pytest.raises(RuntimeError):
