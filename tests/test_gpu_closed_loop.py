@@ -283,8 +283,8 @@ def test_reference_scenarios_driven_by_the_oracle_without_a_budget():
     """The same comparison with every solve run to its iteration caps (the headline's semantics), on a small sample: the CPU
     side of an unbudgeted loop costs up to 0.3 s per solve (CL_B / CL_T enlarge it: 96 x 120 is
     profiles/r06_refscen_oracle_in_the_loop.txt)."""
-    B, T = int(os.environ.get('CL_B', 24)), int(os.environ.get('CL_T', 50))
-    _oracle_in_the_loop("reference", B, T, 0, margins=(0.06, 1.3) if B >= 96 else (0.2, 2.0))
+    B, T = int(os.environ.get('CL_B', 18)), int(os.environ.get('CL_T', 40))
+    _oracle_in_the_loop("reference", B, T, 0, margins=(0.06, 1.3) if B >= 96 else (0.25, 2.5))
 
 
 @pytest.mark.skipif(not os.environ.get("CL_CORRIDOR"), reason="round 5's corridor family: on request (CL_CORRIDOR=1); "
