@@ -37,7 +37,12 @@ oracle, so it lives under ``tests/``; the product package never imports it.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
+
+# threads of the oracle legs: the GPU boxes have >= 16 host cores, this container 8
+HOST_THREADS = max(1, min(16, os.cpu_count() or 8))
 
 LIP_STEP = 1e-4
 TIGHT = dict(tolerance=1e-8, initial_tolerance=1e-8, delta_tolerance=1e-8)
@@ -138,7 +143,7 @@ def audit_pair(head_a, U_a, head_b, U_b, start_tol: float = START_TOL) -> dict:
     return out
 
 
-def divergence_audit(nm, oracle, pr, cfg, P, pairs, opts, reassoc_pairs=(), nthreads: int = 8, start_tol: float = START_TOL) -> dict:
+def divergence_audit(nm, oracle, pr, cfg, P, pairs, opts, reassoc_pairs=(), nthreads: int = HOST_THREADS, start_tol: float = START_TOL) -> dict:
     """Audit of the instances `pairs` (HIP one-wavefront fp64 kernel vs oracle) and `reassoc_pairs` (oracle vs its
     re-associated twin: what the same audit says about two CPU implementations). The oracle's traces run on a thread pool
     (ctypes releases the GIL); a tight-tolerance trace is up to 30 000 iterations."""
@@ -188,7 +193,7 @@ def natural_residual(u, grad, lo, hi):
     return float(np.abs(u - np.clip(u - grad, lo, hi)).max())
 
 
-def oracle_solve_full(oracle, pr, opts, P, idx, nthreads=8, reassoc=False):
+def oracle_solve_full(oracle, pr, opts, P, idx, nthreads=HOST_THREADS, reassoc=False):
     """(U, Y, result records) of the instances `idx`, one oracle.solve each (solve_batch does not hand back the
     multipliers), threads over instances (ctypes releases the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
@@ -283,7 +288,7 @@ def config_for_layout(nm, layout, n_active, **overrides):
     return cfg
 
 
-def run_case(nm, oracle, workload: str, family: str, n: int | None = None, seed: int = 1234, nthreads: int = 8,
+def run_case(nm, oracle, workload: str, family: str, n: int | None = None, seed: int = 1234, nthreads: int = HOST_THREADS,
              tight: bool = True, akkt_form: int = 0, audit: bool = False, audit_max: int = 24, tight_audit: bool | None = None,
              n_tight: int | None = None, n_polish: int | None = None) -> dict:
     """One (configuration, family) row of the table: seeded instances of the BASELINE generator. ``n_polish``: the polish
@@ -301,7 +306,7 @@ def run_case(nm, oracle, workload: str, family: str, n: int | None = None, seed:
                        fixed_point=workload != "cfg4", n_tight=n_tight, P_polish=P_polish)
 
 
-def run_case_on(nm, oracle, P, layout, n_active: int, workload: str, family: str, nthreads: int = 8, tight: bool = True,
+def run_case_on(nm, oracle, P, layout, n_active: int, workload: str, family: str, nthreads: int = HOST_THREADS, tight: bool = True,
                 akkt_form: int = 0, audit: bool = False, audit_max: int = 24, tight_audit: bool | None = None,
                 fixed_point: bool = True, polish: bool = True, n_tight: int | None = None, P_polish=None) -> dict:
     """The protocol on a given parameter batch ``P[n, np]`` (fp64) of the dimensions ``layout`` with at most ``n_active``
@@ -430,7 +435,7 @@ def returned_accuracy(ra, rb) -> dict:
 
 
 def run_protocol(nm, oracle, workloads=("cfg1", "cfg2", "cfg4"), families=FAMILIES, scale: float = 1.0,
-                 nthreads: int = 8, tight: bool = True) -> list:
+                 nthreads: int = HOST_THREADS, tight: bool = True) -> list:
     rows = []
     for w in workloads:
         for f in families:

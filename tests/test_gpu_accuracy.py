@@ -19,7 +19,7 @@ import pytest
 import dyobav_mpcnwta_warehouse_amd as nm
 import oracle
 import accuracy_protocol
-from accuracy_protocol import run_case
+from accuracy_protocol import run_case, HOST_THREADS
 
 pytestmark = pytest.mark.gpu
 
@@ -31,7 +31,7 @@ pytestmark = pytest.mark.gpu
                                                        ("cfg4", "passing", 16, 8)])
 def test_accuracy_protocol(workload, family, n, n_tight):
     passing = family == "passing"
-    row = run_case(nm, oracle, workload, family, n=n, nthreads=8, tight=passing, audit=passing,
+    row = run_case(nm, oracle, workload, family, n=n, nthreads=HOST_THREADS, tight=passing, audit=passing,
                    audit_max=24 if workload != "cfg4" else 4, tight_audit=passing and workload != "cfg4", n_tight=n_tight or None,
                    n_polish=64 if workload == "cfg4" else None)    # (cfg4: ~30 % converge, a third of those is replaced on both sides)
     check_protocol_row(row, workload, passing, n)

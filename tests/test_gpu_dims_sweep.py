@@ -11,6 +11,7 @@ import pytest
 
 import dyobav_mpcnwta_warehouse_amd as nm
 import oracle
+from accuracy_protocol import HOST_THREADS
 from dyobav_mpcnwta_warehouse_amd.scenarios import ParamLayout
 
 pytestmark = pytest.mark.gpu
@@ -56,7 +57,7 @@ def test_short_solves_agree_across_kernels_and_dimensions(N, Ndyn, n_ped, n_hyp)
     P = nm.scenarios.make_batch(8, lay, seed=200 + N + Ndyn, n_ped=n_ped, n_hyp=n_hyp, ped_mode="oncoming")
     pr = oracle.Problem(N, lay.Nother, lay.Nstc, Ndyn)
     short = dict(max_outer_iterations=1, max_inner_iterations=3, lip_eps_f64=1e-4, lip_delta_f64=1e-4)
-    Uo, ro = oracle.solve_batch(pr, oracle.Options(max_outer=1, max_inner=3, lip_delta=1e-4, lip_eps=1e-4), P, nthreads=8)
+    Uo, ro = oracle.solve_batch(pr, oracle.Options(max_outer=1, max_inner=3, lip_delta=1e-4, lip_eps=1e-4), P, nthreads=HOST_THREADS)
     for dtype, tol in ((np.float64, 1e-7), (np.float32, 2e-2)):
         runs = {}
         for name, ov in (("throughput", dict(latency_waves=1, coop_waves=1)), ("latency", dict(latency_waves=3, coop_waves=1)),

@@ -7,6 +7,7 @@ import pytest
 
 import dyobav_mpcnwta_warehouse_amd as nm
 import oracle
+from accuracy_protocol import HOST_THREADS
 import conftest
 from conftest import config_for
 
@@ -31,7 +32,7 @@ def test_akkt_residual_forms_follow_the_oracle(akkt_form):
     P = nm.scenarios.make_batch(48, L, seed=31, n_ped=0, n_boxes=0)
     pr = oracle.Problem()
     op = oracle.Options(lip_delta=1e-4, lip_eps=1e-4, akkt_form=akkt_form, max_outer=3)
-    Uo, ro = oracle.solve_batch(pr, op, P, nthreads=8)
+    Uo, ro = oracle.solve_batch(pr, op, P, nthreads=HOST_THREADS)
     with nm.Handle(config_for(pr, lip_delta_f64=1e-4, lip_eps_f64=1e-4, akkt_form=akkt_form,
                               max_outer_iterations=3)) as h:
         r = h.solve(P)
@@ -48,7 +49,7 @@ def test_akkt_residual_forms_follow_the_oracle(akkt_form):
     assert np.median(du) < 1e-6 and np.mean(du < 1e-4) >= 0.9
     # the option is live: the other form takes a different number of inner iterations
     other = oracle.solve_batch(pr, oracle.Options(lip_delta=1e-4, lip_eps=1e-4, akkt_form=1 - akkt_form, max_outer=3),
-                               P, nthreads=8)[1]
+                               P, nthreads=HOST_THREADS)[1]
     hi, lo = (ro, other) if akkt_form == 1 else (other, ro)
     assert hi["inner_iters"].sum() > 1.5 * lo["inner_iters"].sum()
 
@@ -97,7 +98,7 @@ def test_evaluation_budget_agrees_exactly_with_the_oracle():
     with nm.Handle(config_for(pr, lip_delta_f64=1e-4, lip_eps_f64=1e-4)) as h:
         ref = h.solve(P)
     for E, need in ((3, 1.0), (25, 1.0), (60, 0.95), (150, 0.8)):     # (measured: 1.0, 1.0, 0.98-1.0, 0.86)
-        Uo, ro = oracle.solve_batch(pr, oracle.Options(max_evals=E, **opts), P, nthreads=8)
+        Uo, ro = oracle.solve_batch(pr, oracle.Options(max_evals=E, **opts), P, nthreads=HOST_THREADS)
         with nm.Handle(config_for(pr, lip_delta_f64=1e-4, lip_eps_f64=1e-4, max_evaluations=E)) as h:
             r = h.solve(P)
         same = ((r["status"] == ro["status"]) & (r["iters"][:, 0] == ro["outer_iters"]) & (r["iters"][:, 1] == ro["inner_iters"]) &

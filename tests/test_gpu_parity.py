@@ -15,6 +15,7 @@ import pytest
 
 import dyobav_mpcnwta_warehouse_amd as nm
 import oracle
+from accuracy_protocol import HOST_THREADS
 import conftest
 from conftest import config_for
 
@@ -79,7 +80,7 @@ def test_iterate_path_matches_oracle_f64(family):
     pr = oracle.Problem()
     for max_inner in (1, 3, 10):
         op = oracle.Options(max_outer=1, max_inner=max_inner, lip_delta=1e-4, lip_eps=1e-4)
-        Uo, ro = oracle.solve_batch(pr, op, P, nthreads=8)
+        Uo, ro = oracle.solve_batch(pr, op, P, nthreads=HOST_THREADS)
         cfg = config_for(pr, max_outer_iterations=1, max_inner_iterations=max_inner, lip_delta_f64=1e-4,
                          lip_eps_f64=1e-4)
         with nm.Handle(cfg) as h:
@@ -101,7 +102,7 @@ def test_full_solve_matches_oracle_f64_free_space():
     P = nm.scenarios.make_batch(128, L, seed=22, n_ped=0, n_boxes=0)
     pr = oracle.Problem()
     op = oracle.Options(lip_delta=1e-4, lip_eps=1e-4)
-    Uo, ro = oracle.solve_batch(pr, op, P, nthreads=8)
+    Uo, ro = oracle.solve_batch(pr, op, P, nthreads=HOST_THREADS)
     with nm.Handle(config_for(pr, lip_delta_f64=1e-4, lip_eps_f64=1e-4)) as h:
         r = h.solve(P)
     du = np.abs(r["U"] - Uo).max(axis=1)
@@ -121,7 +122,7 @@ def test_full_solve_f32_statistics_vs_oracle_f64():
     L = nm.scenarios.ParamLayout()
     P = nm.scenarios.make_batch(256, L, seed=23, n_ped=0, n_boxes=0)
     pr = oracle.Problem()
-    Uo, ro = oracle.solve_batch(pr, oracle.Options(), P, nthreads=8)
+    Uo, ro = oracle.solve_batch(pr, oracle.Options(), P, nthreads=HOST_THREADS)
     with nm.Handle(config_for(pr)) as h:
         r = h.solve(P.astype(np.float32))
     assert set(np.unique(r["status"])) <= {0, 1}
@@ -226,7 +227,7 @@ def test_config2_dimensions_40_obstacles():
     P = nm.scenarios.make_batch(32, lay, seed=1, n_ped=4, n_hyp=10)
     pr = oracle.Problem(20, 10, 10, 40)
     op = oracle.Options(max_outer=1, max_inner=5, lip_delta=1e-4, lip_eps=1e-4)
-    Uo, ro = oracle.solve_batch(pr, op, P, nthreads=8)
+    Uo, ro = oracle.solve_batch(pr, op, P, nthreads=HOST_THREADS)
     cfg = config_for(pr, max_outer_iterations=1, max_inner_iterations=5, lip_delta_f64=1e-4, lip_eps_f64=1e-4)
     with nm.Handle(cfg) as h:
         r = h.solve(P)
@@ -273,7 +274,7 @@ def test_config4_long_horizon_obstacle_table_streamed_from_global_memory():
                 assert r["psi"][i] == pytest.approx(v, rel=rp)
                 np.testing.assert_allclose(r["grad"][i], g, rtol=0, atol=rg * np.abs(g).max())
     op = oracle.Options(max_outer=1, max_inner=4, lip_delta=1e-4, lip_eps=1e-4)
-    Uo, ro = oracle.solve_batch(pr, op, P, nthreads=8)
+    Uo, ro = oracle.solve_batch(pr, op, P, nthreads=HOST_THREADS)
     cfg = config_for(pr, max_outer_iterations=1, max_inner_iterations=4, lip_delta_f64=1e-4, lip_eps_f64=1e-4)
     with nm.Handle(cfg) as h:
         r = h.solve(P)
@@ -337,7 +338,7 @@ def test_config4_compressed_global_table(axis):
                 assert r["psi"][i] == pytest.approx(v, rel=rp)
                 np.testing.assert_allclose(r["grad"][i], g, rtol=0, atol=rg * np.abs(g).max())
     op = oracle.Options(max_outer=1, max_inner=4, lip_delta=1e-4, lip_eps=1e-4)
-    Uo, ro = oracle.solve_batch(pr, op, P, nthreads=8)
+    Uo, ro = oracle.solve_batch(pr, op, P, nthreads=HOST_THREADS)
     cfg = config_for(pr, max_outer_iterations=1, max_inner_iterations=4, lip_delta_f64=1e-4, lip_eps_f64=1e-4, **ov)
     with nm.Handle(cfg) as h:
         r = h.solve(P)
@@ -348,7 +349,7 @@ def test_config4_compressed_global_table(axis):
         Pr = P.copy()
         Pr[3, lay.od + 6 * (5 * 41 + 7) + 4] = 0.3          # (angle; with rx != ry: a rotated CIRCLE is still axis-aligned)
         Pr[3, lay.od + 6 * (5 * 41 + 7) + 2] *= 1.5
-        Uor, _ = oracle.solve_batch(pr, op, Pr, nthreads=8)
+        Uor, _ = oracle.solve_batch(pr, op, Pr, nthreads=HOST_THREADS)
         rr = h.solve(Pr)
         if axis == 1:
             assert rr["status"][3] == 5 and np.isnan(rr["U"][3]).all()
