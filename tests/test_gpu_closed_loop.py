@@ -130,7 +130,7 @@ def test_parity_protocol_on_the_closed_loop_distribution():
     conv = row["converged_frac"]["hip64"]
     # the closed loop is NOT the contract family: a good share of the solves the reference would actually run converges
     assert conv >= 0.25, row["converged_frac"]
-    check_protocol_row(row, "cfg2", True, 72)
+    check_protocol_row(row, "cfg2", True, 72, min_both_kkt=5)   # (24 tight instances: 7-8 stationary on both sides)
 
 
 def test_parity_protocol_on_the_reference_scenarios():
