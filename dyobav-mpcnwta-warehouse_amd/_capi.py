@@ -47,7 +47,7 @@ class NmpcConfigStruct(C.Structure):
         ("polish", C.c_int32), ("polish_max_outer_iterations", C.c_int32), ("polish_max_inner_iterations", C.c_int32),
         ("staged_evals", C.c_int32),
         ("polish_tolerance", C.c_double), ("polish_delta_tolerance", C.c_double),
-        ("max_evaluations", C.c_int32), ("tail_latency", C.c_int32),
+        ("max_evaluations", C.c_int32), ("tail_latency", C.c_int32), ("batch_invariant", C.c_int32),
     ]
 
 

@@ -923,6 +923,12 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
     pl.fn = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs) : pick_solve<T>(h->lps, L.glb, L.rs);
     pl.has_axis = L.rs > 0 && h->lps == 3 && !L.glb;
     if (pl.has_axis) pl.fn2 = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs, 2) : pick_solve<T>(h->lps, L.glb, L.rs, 2);
+    // nmpc_config.batch_invariant: the latency plan on the TAIL members -- the throughput kernels' evaluation, hence their bits
+    if (waves && h->cfg.batch_invariant > 0)
+        if (SolveFn<T> tf = pick_solve_tail<T>(h->lps, L.glb, L.rs, 1)) {
+            pl.fn = tf;
+            if (pl.has_axis) pl.fn2 = pick_solve_tail<T>(h->lps, L.glb, L.rs, 2);
+        }
     pl.uses_ws = L.glb;
     if (coop > 1) {
         // global table: the pair (compressed table of axis-aligned ellipses / general table); LDS table: one kernel
@@ -1742,6 +1748,7 @@ int nmpc_default_config(nmpc_config* c)
     c->polish_delta_tolerance = 1e-5;
     c->max_evaluations = 0;
     c->tail_latency = 0;
+    c->batch_invariant = 0;
     return 0;
 }
 
@@ -1796,6 +1803,8 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "max_solver_time_us < 0");
     if (cfg->max_evaluations < 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "max_evaluations = %d < 0", cfg->max_evaluations);
     if (cfg->tail_latency < -1) return fail(NMPC_ERR_INVALID_ARGUMENT, "tail_latency = %d < -1", cfg->tail_latency);
+    if (cfg->batch_invariant != 0 && cfg->batch_invariant != 1)
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "batch_invariant = %d (0 or 1)", cfg->batch_invariant);
     if (cfg->staged_evals < -1) return fail(NMPC_ERR_INVALID_ARGUMENT, "staged_evals = %d < -1", cfg->staged_evals);
     if (cfg->axis_aligned < -1 || cfg->axis_aligned > 1)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "axis_aligned = %d (0 automatic, 1 promised, -1 never)", cfg->axis_aligned);

@@ -36,25 +36,25 @@ def test_config_struct_matches_header_defaults():
     assert cfg.coop_waves == 0 and cfg.axis_aligned == 0 and cfg.reg_table == 0 and cfg.staged == 0
     assert cfg.polish == 0 and cfg.polish_max_outer_iterations == 4 and cfg.polish_max_inner_iterations == 150
     assert cfg.polish_tolerance == 1e-6 and cfg.polish_delta_tolerance == 1e-5 and cfg.staged_evals == 0
-    assert cfg.max_evaluations == 0 and cfg.tail_latency == 0
+    assert cfg.max_evaluations == 0 and cfg.tail_latency == 0 and cfg.batch_invariant == 0
     # struct size and a late field's offset: ctypes mirror vs the C compiler on include/nmpc_hip.h (catches field drift)
     import subprocess, tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "sz.c")
-        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "nmpc_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu", '
+        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "nmpc_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu", '
                              'sizeof(nmpc_config), offsetof(nmpc_config, latency_waves), offsetof(nmpc_config, initial_penalty), offsetof(nmpc_config, reg_table), '
-                             'offsetof(nmpc_config, polish_delta_tolerance), offsetof(nmpc_config, max_evaluations), sizeof(nmpc_layout_info), sizeof(nmpc_loop_args), offsetof(nmpc_loop_args, n_hyp), '
+                             'offsetof(nmpc_config, polish_delta_tolerance), offsetof(nmpc_config, max_evaluations), offsetof(nmpc_config, batch_invariant), sizeof(nmpc_layout_info), sizeof(nmpc_loop_args), offsetof(nmpc_loop_args, n_hyp), '
                              'offsetof(nmpc_loop_args, hyp_radius_growth), sizeof(nmpc_assemble_args));return 0;}\n')
         exe = os.path.join(td, "sz")
         subprocess.run(["gcc", "-I", os.path.join(root, "include"), src, "-o", exe], check=True)
-        size, off_lw, off_ip, off_gram, off_pd, off_me, size_li, size_loop, off_nh, off_hg, size_asm = map(
+        size, off_lw, off_ip, off_gram, off_pd, off_me, off_bi, size_li, size_loop, off_nh, off_hg, size_asm = map(
             int, subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split())
-    assert ctypes.sizeof(nm.NmpcConfigStruct) == size == 6 * 4 + 13 * 8 + 4 * 4 + 11 * 8 + 2 * 4 + 8 + 4 * 4 + 4 * 4 + 2 * 8 + 2 * 4
+    assert ctypes.sizeof(nm.NmpcConfigStruct) == size == 6 * 4 + 13 * 8 + 4 * 4 + 11 * 8 + 2 * 4 + 8 + 4 * 4 + 4 * 4 + 2 * 8 + 3 * 4 + 4   # (+ 4: tail padding)
     assert nm.NmpcConfigStruct.latency_waves.offset == off_lw and nm.NmpcConfigStruct.initial_penalty.offset == off_ip
     assert nm.NmpcConfigStruct.reg_table.offset == off_gram
     assert nm.NmpcConfigStruct.polish_delta_tolerance.offset == off_pd
-    assert nm.NmpcConfigStruct.max_evaluations.offset == off_me  # ABI v5
+    assert nm.NmpcConfigStruct.max_evaluations.offset == off_me and nm.NmpcConfigStruct.batch_invariant.offset == off_bi  # ABI v5
     from dyobav_mpcnwta_warehouse_amd._capi import NmpcAssembleArgs, NmpcLayoutInfo, NmpcLoopArgs
     assert ctypes.sizeof(NmpcLayoutInfo) == size_li
     # ABI v4: the hypothesis fan of nmpc_loop_args (n_hyp in the former `reserved` slot + three doubles at the end)
