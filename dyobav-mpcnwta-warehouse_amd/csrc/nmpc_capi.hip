@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -877,6 +878,12 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
         // ones and the faster line search of the long ones wins: 41.8 k (W = 4) against 40.0 k (W = 3) and 35.4 k (W = 2),
         // `passing` 46.6 / 41.8 / 34.7 k -- profiles/r04_exp_cfg1_waves.txt. Results do not depend on W, bit for bit.)
         lw = B <= cap ? (sizeof(T) == 4 ? (L.rs >= kRegSlotsLarge ? 2 : kSpecWaves) : kSpecWaves) : B <= 4 * cap ? 2 : 1;
+        // (14-slot kernels, two wavefronts per SIMD: from ONE device fill on -- 2 048 instances -- the throughput kernels with
+        //  the resumable solve and the tail hand-off are ahead of two wavefronts per instance: configs[2]'s dimensions,
+        //  B = 2 100 / 3 200 / 4 096: `passing` 34.5 / 50.7 / 43.8 -> 22.3 / 30.3 / 28.3 ms, reference scenarios 40.0 / 49.7 /
+        //  50.3 -> 37.4 / 38.6 / 39.5, contract family 73.6 / 94.2 / ~100 -> 56.2 / 70.2 / 87.1; below a fill the two are
+        //  level. The 4- and 6-slot kernels keep the latency plan up to 4 096: level or ahead there. tools/exp_mid_batches.py)
+        if (sizeof(T) == 4 && L.rs >= kRegSlotsLarge && !L.glb && B >= 2 * cap) lw = 1;
         // At most one workgroup per CU (what a fleet's real-time loop sends: a handful of robots): six wavefronts -- the master
         // and five workers, the Lipschitz evaluation + five candidates in the first round of an iteration (1.3 instead of 1.6-1.8
         // rounds per iteration on the long instances). B = 64 / 256: 23.4 -> 21.8 / 18.5 -> 17.3 ms; from two workgroups per CU
@@ -1042,6 +1049,24 @@ int prepare_axis(nmpc_handle_s* h, bool has_axis, nmpc::KParams<T>& k, int B)
 
 // Solve B instances whose buffers (all on the device) are in `k`: kernel choice, the axis-aligned twin, the two-launch
 // resumable solve. `allow_staging`: the caller's status array may be used for the in-progress marker.
+// (development builds, -DNMPC_DEV_ENV: the batch-size thresholds of the resumable solve / the tail hand-off, in device fills, from
+//  the environment -- tools/exp_mid_batches.py; the shipped library has the constants)
+#ifdef NMPC_DEV_ENV
+static double dev_factor(const char* name, double dflt)
+{
+    const char* s = getenv(name);
+    return s ? atof(s) : dflt;
+}
+#else
+static constexpr double dev_factor(const char*, double dflt) { return dflt; }
+#endif
+// Batch size, in device fills of the planned kernel, from which the resumable solve (pilot + ranking) and the tail hand-off are
+// used. fp32 register-table kernels: ONE fill -- measured at configs[1]'s and configs[2]'s dimensions on three families
+// (tools/exp_mid_batches.py, profiles/r06_exp_mid_batches.txt: batches of 1-4 fills, what a closed-loop evaluation sends once
+// most scenarios have finished, -15..-35 %; until round 6 both started at four fills). Everything else: four, as measured
+// in rounds 3-4 (fp64 and the LDS-table kernels have no tail member and were not re-measured).
+constexpr double kStageFills = 4, kTailFills = 4, kStageFillsReg = 1, kTailFillsReg = 1;
+
 template <typename T>
 int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
 {
@@ -1073,8 +1098,9 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
     const int resident = std::max(1, std::min<int>(wpe_tp * h->n_simd,
                                                    (int)(kLdsLimit / ((size_t)L.lds_total * sizeof(T))) * (h->n_simd / 4)));
     const int lat_cap = sizeof(T) == 4 ? h->n_simd : h->n_simd / 2;
+    const bool reg32 = sizeof(T) == 4 && L.rs > 0 && !L.glb;
     if (caps[0] == 0)
-        caps[0] = ((pl.mode == 0 && B >= 4 * (pl.resident ? pl.resident : resident)) || (pl.mode == 1 && B > lat_cap / 2 && B <= lat_cap) ||
+        caps[0] = ((pl.mode == 0 && B >= dev_factor("NMPC_STAGE_FILLS", reg32 ? kStageFillsReg : kStageFills) * (pl.resident ? pl.resident : resident)) || (pl.mode == 1 && B > lat_cap / 2 && B <= lat_cap) ||
                    (pl.mode == 2 && !pl.uses_ws && B >= 4 * pl.resident)) ? 1 : -1; // (configs[4] fp32: 2 116 -> 2 087 ms;
                                                                                    //  streamed table, fp64: -2 %, off)
     if (caps[1] == 0) caps[1] = -1;
@@ -1103,7 +1129,7 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
     int park = h->cfg.tail_latency;
     const int tail_waves = kSpecWaves;
     if (park == 0) park = std::max(32, h->n_simd / 4);      // automatic: one tail workgroup per CU (its four wavefronts alone on their SIMDs)
-    const bool big = B >= 4 * (pl.resident ? pl.resident : resident);
+    const bool big = B >= dev_factor("NMPC_TAIL_FILLS", reg32 ? kTailFillsReg : kTailFills) * (pl.resident ? pl.resident : resident);
     const Plan<T> tail = (park > 0 && allow_staging && k.status && pl.stageable && (n_stage > 0 || (k.order && big)) && B >= 8 * park)
                              ? plan_tail<T>(h, pl, L, tail_waves) : Plan<T>();
     if (n_stage == 0 && !tail.fn) return launch_plan<T>(h, pl, k, B);

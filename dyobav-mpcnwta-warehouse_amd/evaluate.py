@@ -120,13 +120,19 @@ class BatchEvaluator:
         # (obstacle table streamed from global memory -- e.g. N = 40, 160 rows: the library's automatic choice there is
         #  the cooperative kernel, whatever the batch size; pinning latency_waves would switch it off)
         if config.latency_waves == 0 and not streamed and (robot_starts.shape[0] > 1024 if compact is None else compact):
-            # The batch shrinks as scenarios finish (compaction) and the library's automatic choice between its two
-            # solver kernels follows the batch size; the kernels agree to rounding only, so the choice is fixed here
-            # from the initial batch: a scenario's closed-loop trajectory must not depend on who else is still running.
+            # The batch shrinks as scenarios finish (compaction) and the library's automatic choice between its kernel
+            # families follows the batch size. A scenario's closed-loop trajectory must not depend on who else is still
+            # running, so either every plan computes the same bits -- fp32 with the obstacle table in registers:
+            # nmpc_config.batch_invariant, and the library goes on choosing the fastest plan for what is left (latency
+            # kernels for the last few hundred scenarios) -- or, where the families agree to rounding only (fp64, LDS
+            # table), the family is fixed here from the initial batch.
             import copy
             config = copy.copy(config)
-            n_simd = 4 * self.torch.cuda.get_device_properties(self.dev).multi_processor_count
-            config.latency_waves = 1 if robot_starts.shape[0] > 4 * n_simd else 2
+            if self.dt == np.float32 and li.reg_slots_f32 > 0:
+                config.batch_invariant = 1
+            else:
+                n_simd = 4 * self.torch.cuda.get_device_properties(self.dev).multi_processor_count
+                config.latency_waves = 1 if robot_starts.shape[0] > 4 * n_simd else 2
             self.cfg = config
         self.h = _capi.Handle(config)
         self.h.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
