@@ -76,8 +76,8 @@ def test_automatic_choice_follows_batch_size():
     table), small batches four (round 4: with the long instances started first the faster line search wins over what stays
     resident together) -- also with the 15 rows of the shipped yaml and no capacity hint, which run on the 6-slot register
     table at the same register budget (round 5); 2 with the 14-slot register table (more than 18 rows), whose kernels run two
-    wavefronts per SIMD; mid-size batches 2, large ones the throughput kernel (info[7] = wavefronts per instance, 0 =
-    throughput kernel)."""
+    wavefronts per SIMD; mid-size batches 2, large ones the throughput kernel -- from 2 048 instances on with the 14-slot table
+    (info[7] = wavefronts per instance, 0 = throughput kernel)."""
     P_small = nm.scenarios.make_batch(32, seed=37)
     for hint, dtype, expect in ((10, np.float32, 6), (0, np.float32, 6), (0, np.float64, 4)):
         cfg = nm.default_config_struct()
@@ -103,8 +103,19 @@ def test_automatic_choice_follows_batch_size():
     h = nm.Handle(cfg)
     mid = h.solve(nm.scenarios.make_batch(2048, seed=37, n_ped=0, n_boxes=0).astype(np.float32), dtype=np.float32)
     big = h.solve(nm.scenarios.make_batch(8192, seed=37, n_ped=0, n_boxes=0).astype(np.float32), dtype=np.float32)
+    fam_big = h.last_launch_info()["family"]
     h.close()
-    assert (mid["info"][:, 7] == 2).all() and (big["info"][:, 7] == 0).all()
+    # (the throughput plan from one device fill on hands the drain phase of its last launch to the latency family's tail
+    #  member, nmpc_config.tail_latency: the few instances finished there report its four wavefronts)
+    assert (mid["info"][:, 7] == 2).all() and fam_big == "throughput" and (big["info"][:, 7] == 0).mean() > 0.9
+    assert set(np.unique(big["info"][:, 7])) <= {0, 4}
+    # 14-slot kernels (two wavefronts per SIMD): the throughput plan takes over at one device fill, 2 048 instances
+    cfg = nm.default_config_struct()
+    cfg.latency_waves, cfg.Ndynobs = 0, 24
+    with nm.Handle(cfg) as h:
+        for B, fam in ((1500, "latency"), (2100, "throughput")):
+            h.solve(nm.scenarios.make_batch(B, lay24, seed=37, n_ped=4, n_hyp=5).astype(np.float32), dtype=np.float32)
+            assert h.last_launch_info()["family"] == fam, (B, h.last_launch_info())
 
 
 def test_latency_kernel_agrees_with_throughput_kernel_to_rounding():
