@@ -877,7 +877,11 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
         // solve starts the long instances first, the quarter of the workgroups that has to wait for a slot is the short
         // ones and the faster line search of the long ones wins: 41.8 k (W = 4) against 40.0 k (W = 3) and 35.4 k (W = 2),
         // `passing` 46.6 / 41.8 / 34.7 k -- profiles/r04_exp_cfg1_waves.txt. Results do not depend on W, bit for bit.)
-        lw = B <= cap ? (sizeof(T) == 4 ? (L.rs >= kRegSlotsLarge ? 2 : kSpecWaves) : kSpecWaves) : B <= 4 * cap ? 2 : 1;
+        lw = B <= cap ? (sizeof(T) == 4 ? (L.rs >= kRegSlotsLarge ? (4 * B <= 3 * h->n_simd ? kSpecWaves : 2) : kSpecWaves) : kSpecWaves) : B <= 4 * cap ? 2 : 1;
+        // (14-slot kernels, 2 048 resident wavefronts: until round 6 two wavefronts per instance at every size. Measured at
+        //  configs[2]'s dimensions on three families, W = 2 / 3 / 4 / 6 -- profiles/r06_exp_mid_batches.txt: B = 64 / 256 six
+        //  wavefronts -32..-35 %; B = 512 / 768 four -25..-30 % on `passing` and the reference scenarios, -31 % / +3 % on the
+        //  contract family; at B = 1 024 four still win 27-30 % on the first two but lose 14 % on the contract family: two.)
         // (14-slot kernels, two wavefronts per SIMD: from ONE device fill on -- 2 048 instances -- the throughput kernels with
         //  the resumable solve and the tail hand-off are ahead of two wavefronts per instance: configs[2]'s dimensions,
         //  B = 2 100 / 3 200 / 4 096: `passing` 34.5 / 50.7 / 43.8 -> 22.3 / 30.3 / 28.3 ms, reference scenarios 40.0 / 49.7 /
@@ -890,8 +894,9 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
         // on (B = 512) six or eight wavefronts cost more than they bring
         // (profiles/r04_exp_cfg1_batch_size_and_up_to_8_wavefronts.txt). Same results, bit for bit.
         // (the 4-slot register table only: what was measured, and what nmpc_hip.h documents -- ADVICE r4)
-        // (the 6-slot table, same register budget: measured too -- B = 64 / 256: 22.98 -> 21.37 / 18.12 -> 16.96 ms, tools/exp_mid_w6.py)
-        if (sizeof(T) == 4 && (L.rs == kRegSlotsSmall || L.rs == kRegSlotsMid) && !L.glb && 4 * B <= h->n_simd) lw = kSpecWavesWide;
+        // (the 6-slot table, same register budget: measured too -- B = 64 / 256: 22.98 -> 21.37 / 18.12 -> 16.96 ms, tools/exp_mid_w6.py;
+        //  the 14-slot table: round 6, below)
+        if (sizeof(T) == 4 && L.rs > 0 && !L.glb && 4 * B <= h->n_simd) lw = kSpecWavesWide;
         // Large batches whose LDS tables allow only a few workgroups per CU (e.g. 40 active obstacle rows: 35 KB,
         // 4 per CU = one wavefront per SIMD): the wavefronts of a latency-kernel workgroup SHARE the instance's
         // tables, so W of them fill the SIMDs that the throughput kernel leaves empty (measured on configs[2]:

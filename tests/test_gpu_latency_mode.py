@@ -75,8 +75,8 @@ def test_automatic_choice_follows_batch_size():
     """latency_waves = 0: batches of at most one workgroup per CU get six wavefronts per instance (fp32, 4- or 6-slot register
     table), small batches four (round 4: with the long instances started first the faster line search wins over what stays
     resident together) -- also with the 15 rows of the shipped yaml and no capacity hint, which run on the 6-slot register
-    table at the same register budget (round 5); 2 with the 14-slot register table (more than 18 rows), whose kernels run two
-    wavefronts per SIMD; mid-size batches 2, large ones the throughput kernel -- from 2 048 instances on with the 14-slot table
+    table at the same register budget (round 5); with the 14-slot register table (more than 18 rows), whose kernels run two
+    wavefronts per SIMD, six / four / two up to 256 / 768 / 2 047 instances (round 6); mid-size batches 2, large ones the throughput kernel -- from 2 048 instances on with the 14-slot table
     (info[7] = wavefronts per instance, 0 = throughput kernel)."""
     P_small = nm.scenarios.make_batch(32, seed=37)
     for hint, dtype, expect in ((10, np.float32, 6), (0, np.float32, 6), (0, np.float64, 4)):
@@ -91,7 +91,7 @@ def test_automatic_choice_follows_batch_size():
     cfg.latency_waves, cfg.Ndynobs = 0, 24
     with nm.Handle(cfg) as h:
         r24 = h.solve(nm.scenarios.make_batch(32, lay24, seed=37, n_ped=4, n_hyp=5).astype(np.float32), dtype=np.float32)
-    assert (r24["info"][:, 7] == 2).all(), r24["info"][0, 7]
+    assert (r24["info"][:, 7] == 6).all(), r24["info"][0, 7]
     cfg = nm.default_config_struct()
     cfg.latency_waves = 0
     cfg.max_active_dynobs = 10
@@ -113,9 +113,9 @@ def test_automatic_choice_follows_batch_size():
     cfg = nm.default_config_struct()
     cfg.latency_waves, cfg.Ndynobs = 0, 24
     with nm.Handle(cfg) as h:
-        for B, fam in ((1500, "latency"), (2100, "throughput")):
-            h.solve(nm.scenarios.make_batch(B, lay24, seed=37, n_ped=4, n_hyp=5).astype(np.float32), dtype=np.float32)
-            assert h.last_launch_info()["family"] == fam, (B, h.last_launch_info())
+        for B, fam, w in ((600, "latency", 4), (1000, "latency", 2), (1500, "latency", 2), (2100, "throughput", 0)):
+            r = h.solve(nm.scenarios.make_batch(B, lay24, seed=37, n_ped=4, n_hyp=5).astype(np.float32), dtype=np.float32)
+            assert h.last_launch_info()["family"] == fam and (w == 0 or (r["info"][:, 7] == w).all()), (B, h.last_launch_info())
 
 
 def test_latency_kernel_agrees_with_throughput_kernel_to_rounding():
