@@ -848,6 +848,29 @@ int stage_out(nmpc_handle_s* h, DevBuf& buf, T* dst, size_t count, T** dev, bool
 }
 
 // ---- kernel choice and launch ---------------------------------------------------------------------------------------
+// (development builds, -DNMPC_DEV_ENV: the batch-size thresholds of the resumable solve / the tail hand-off, in device fills, from
+//  the environment -- tools/exp_mid_batches.py; the shipped library has the constants)
+#ifdef NMPC_DEV_ENV
+static double dev_factor(const char* name, double dflt)
+{
+    const char* s = getenv(name);
+    return s ? atof(s) : dflt;
+}
+#else
+static constexpr double dev_factor(const char*, double dflt) { return dflt; }
+#endif
+// Batch size, in device fills of the planned kernel, from which the resumable solve (pilot + ranking) and the tail hand-off are
+// used. fp32 register-table kernels: ONE fill -- measured at configs[1]'s and configs[2]'s dimensions on three families
+// (tools/exp_mid_batches.py, profiles/r06_exp_mid_batches.txt: batches of 1-4 fills, what a closed-loop evaluation sends once
+// most scenarios have finished, -15..-35 %; until round 6 both started at four fills). Everything else: four, as measured
+// in rounds 3-4 (fp64 and the LDS-table kernels have no tail member and were not re-measured).
+constexpr double kStageFills = 4, kTailFills = 4, kStageFillsReg = 1, kTailFillsReg = 1;
+// 14-slot kernels (2 048 resident wavefronts): already from 0.7 fills on -- B = 1 500 at configs[2]'s dimensions: `passing` 42.0 ->
+// 27.2 ms, reference scenarios 31.0 -> 32.5, contract family 62.2 -> 50.5; at 1 024 the contract family still loses 20 % to two
+// wavefronts per instance, and at configs[1]'s dimensions (4-slot kernels) it does so up to a full fill (same record).
+constexpr double kFillsLarge = 0.7;
+constexpr double kTailMinParks = 5;   // the hand-off needs a batch of at least this many parking thresholds (8 until the above)
+
 template <typename T>
 struct Plan {
     SolveFn<T> fn = nullptr, fn2 = nullptr; // fn2: the general-path member of a register-table kernel pair (fn = the axis-aligned one)
@@ -882,12 +905,12 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
         //  configs[2]'s dimensions on three families, W = 2 / 3 / 4 / 6 -- profiles/r06_exp_mid_batches.txt: B = 64 / 256 six
         //  wavefronts -32..-35 %; B = 512 / 768 four -25..-30 % on `passing` and the reference scenarios, -31 % / +3 % on the
         //  contract family; at B = 1 024 four still win 27-30 % on the first two but lose 14 % on the contract family: two.)
-        // (14-slot kernels, two wavefronts per SIMD: from ONE device fill on -- 2 048 instances -- the throughput kernels with
+        // (14-slot kernels, two wavefronts per SIMD: from 0.7 device fills on -- 1 434 instances, kFillsLarge -- the throughput kernels with
         //  the resumable solve and the tail hand-off are ahead of two wavefronts per instance: configs[2]'s dimensions,
         //  B = 2 100 / 3 200 / 4 096: `passing` 34.5 / 50.7 / 43.8 -> 22.3 / 30.3 / 28.3 ms, reference scenarios 40.0 / 49.7 /
         //  50.3 -> 37.4 / 38.6 / 39.5, contract family 73.6 / 94.2 / ~100 -> 56.2 / 70.2 / 87.1; below a fill the two are
         //  level. The 4- and 6-slot kernels keep the latency plan up to 4 096: level or ahead there. tools/exp_mid_batches.py)
-        if (sizeof(T) == 4 && L.rs >= kRegSlotsLarge && !L.glb && B >= 2 * cap) lw = 1;
+        if (sizeof(T) == 4 && L.rs >= kRegSlotsLarge && !L.glb && B >= kFillsLarge * 2 * cap) lw = 1;
         // At most one workgroup per CU (what a fleet's real-time loop sends: a handful of robots): six wavefronts -- the master
         // and five workers, the Lipschitz evaluation + five candidates in the first round of an iteration (1.3 instead of 1.6-1.8
         // rounds per iteration on the long instances). B = 64 / 256: 23.4 -> 21.8 / 18.5 -> 17.3 ms; from two workgroups per CU
@@ -1054,24 +1077,6 @@ int prepare_axis(nmpc_handle_s* h, bool has_axis, nmpc::KParams<T>& k, int B)
 
 // Solve B instances whose buffers (all on the device) are in `k`: kernel choice, the axis-aligned twin, the two-launch
 // resumable solve. `allow_staging`: the caller's status array may be used for the in-progress marker.
-// (development builds, -DNMPC_DEV_ENV: the batch-size thresholds of the resumable solve / the tail hand-off, in device fills, from
-//  the environment -- tools/exp_mid_batches.py; the shipped library has the constants)
-#ifdef NMPC_DEV_ENV
-static double dev_factor(const char* name, double dflt)
-{
-    const char* s = getenv(name);
-    return s ? atof(s) : dflt;
-}
-#else
-static constexpr double dev_factor(const char*, double dflt) { return dflt; }
-#endif
-// Batch size, in device fills of the planned kernel, from which the resumable solve (pilot + ranking) and the tail hand-off are
-// used. fp32 register-table kernels: ONE fill -- measured at configs[1]'s and configs[2]'s dimensions on three families
-// (tools/exp_mid_batches.py, profiles/r06_exp_mid_batches.txt: batches of 1-4 fills, what a closed-loop evaluation sends once
-// most scenarios have finished, -15..-35 %; until round 6 both started at four fills). Everything else: four, as measured
-// in rounds 3-4 (fp64 and the LDS-table kernels have no tail member and were not re-measured).
-constexpr double kStageFills = 4, kTailFills = 4, kStageFillsReg = 1, kTailFillsReg = 1;
-
 template <typename T>
 int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
 {
@@ -1105,7 +1110,7 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
     const int lat_cap = sizeof(T) == 4 ? h->n_simd : h->n_simd / 2;
     const bool reg32 = sizeof(T) == 4 && L.rs > 0 && !L.glb;
     if (caps[0] == 0)
-        caps[0] = ((pl.mode == 0 && B >= dev_factor("NMPC_STAGE_FILLS", reg32 ? kStageFillsReg : kStageFills) * (pl.resident ? pl.resident : resident)) || (pl.mode == 1 && B > lat_cap / 2 && B <= lat_cap) ||
+        caps[0] = ((pl.mode == 0 && B >= dev_factor("NMPC_STAGE_FILLS", !reg32 ? kStageFills : L.rs >= kRegSlotsLarge ? kFillsLarge : kStageFillsReg) * (pl.resident ? pl.resident : resident)) || (pl.mode == 1 && B > lat_cap / 2 && B <= lat_cap) ||
                    (pl.mode == 2 && !pl.uses_ws && B >= 4 * pl.resident)) ? 1 : -1; // (configs[4] fp32: 2 116 -> 2 087 ms;
                                                                                    //  streamed table, fp64: -2 %, off)
     if (caps[1] == 0) caps[1] = -1;
@@ -1132,10 +1137,12 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
     // workgroup never finds its four slots on one CU and runs after the throughput launch -- profiles/r06_ab_tail_handoff.jsonl.)
     h->last_tail = 0;
     int park = h->cfg.tail_latency;
-    const int tail_waves = kSpecWaves;
-    if (park == 0) park = std::max(32, h->n_simd / 4);      // automatic: one tail workgroup per CU (its four wavefronts alone on their SIMDs)
-    const bool big = B >= dev_factor("NMPC_TAIL_FILLS", reg32 ? kTailFillsReg : kTailFills) * (pl.resident ? pl.resident : resident);
-    const Plan<T> tail = (park > 0 && allow_staging && k.status && pl.stageable && (n_stage > 0 || (k.order && big)) && B >= 8 * park)
+    if (park == 0) park = std::max(32, h->n_simd / 4);      // automatic: one tail workgroup per CU
+    // (six wavefronts per parked instance while they are all resident at two per SIMD, else four: `passing` 87.0 -> 84.4 ms per
+    //  call, batches of 3 000 / 6 000: -8 / -6 %; eight bring nothing more -- profiles/r06_exp_mid_batches.txt)
+    const int tail_waves = (int)dev_factor("NMPC_TAIL_WAVES", park * kSpecWavesWide <= 2 * h->n_simd ? kSpecWavesWide : kSpecWaves);
+    const bool big = B >= dev_factor("NMPC_TAIL_FILLS", !reg32 ? kTailFills : L.rs >= kRegSlotsLarge ? kFillsLarge : kTailFillsReg) * (pl.resident ? pl.resident : resident);
+    const Plan<T> tail = (park > 0 && allow_staging && k.status && pl.stageable && (n_stage > 0 || (k.order && big)) && B >= dev_factor("NMPC_TAIL_MINB", kTailMinParks) * park)
                              ? plan_tail<T>(h, pl, L, tail_waves) : Plan<T>();
     if (n_stage == 0 && !tail.fn) return launch_plan<T>(h, pl, k, B);
     if (tail.fn) {

@@ -76,7 +76,7 @@ def test_automatic_choice_follows_batch_size():
     table), small batches four (round 4: with the long instances started first the faster line search wins over what stays
     resident together) -- also with the 15 rows of the shipped yaml and no capacity hint, which run on the 6-slot register
     table at the same register budget (round 5); with the 14-slot register table (more than 18 rows), whose kernels run two
-    wavefronts per SIMD, six / four / two up to 256 / 768 / 2 047 instances (round 6); mid-size batches 2, large ones the throughput kernel -- from 2 048 instances on with the 14-slot table
+    wavefronts per SIMD, six / four / two up to 256 / 768 / 1 433 instances (round 6); mid-size batches 2, large ones the throughput kernel -- from 1 434 instances on with the 14-slot table
     (info[7] = wavefronts per instance, 0 = throughput kernel)."""
     P_small = nm.scenarios.make_batch(32, seed=37)
     for hint, dtype, expect in ((10, np.float32, 6), (0, np.float32, 6), (0, np.float64, 4)):
@@ -106,14 +106,14 @@ def test_automatic_choice_follows_batch_size():
     fam_big = h.last_launch_info()["family"]
     h.close()
     # (the throughput plan from one device fill on hands the drain phase of its last launch to the latency family's tail
-    #  member, nmpc_config.tail_latency: the few instances finished there report its four wavefronts)
+    #  member, nmpc_config.tail_latency: the few instances finished there report its six wavefronts)
     assert (mid["info"][:, 7] == 2).all() and fam_big == "throughput" and (big["info"][:, 7] == 0).mean() > 0.9
-    assert set(np.unique(big["info"][:, 7])) <= {0, 4}
-    # 14-slot kernels (two wavefronts per SIMD): the throughput plan takes over at one device fill, 2 048 instances
+    assert set(np.unique(big["info"][:, 7])) <= {0, 6}
+    # 14-slot kernels (two wavefronts per SIMD, 2 048 resident): the throughput plan takes over at 0.7 device fills, 1 434 instances
     cfg = nm.default_config_struct()
     cfg.latency_waves, cfg.Ndynobs = 0, 24
     with nm.Handle(cfg) as h:
-        for B, fam, w in ((600, "latency", 4), (1000, "latency", 2), (1500, "latency", 2), (2100, "throughput", 0)):
+        for B, fam, w in ((600, "latency", 4), (1000, "latency", 2), (1400, "latency", 2), (1500, "throughput", 0), (2100, "throughput", 0)):
             r = h.solve(nm.scenarios.make_batch(B, lay24, seed=37, n_ped=4, n_hyp=5).astype(np.float32), dtype=np.float32)
             assert h.last_launch_info()["family"] == fam and (w == 0 or (r["info"][:, 7] == w).all()), (B, h.last_launch_info())
 

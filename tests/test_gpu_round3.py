@@ -109,8 +109,11 @@ def test_staged_solve_is_bit_identical_to_the_one_launch_solve(dtype, ov):
             base = r
             assert (r["iters"][:, 0] > 4).sum() > B // 10       # instances that cross every stage boundary
             continue
-        for k in ("U", "cost", "status", "iters", "y", "info"):
+        for k in ("U", "cost", "status", "iters", "y"):
             assert np.array_equal(r[k], base[k]), (staged, k)
+        # (info[6], [7] are launch diagnostics: from 1 280 instances on the staged fp32 solve hands its drain phase to the
+        #  tail member, whose wavefront count info[7] reports -- tests/test_gpu_tail.py)
+        assert np.array_equal(r["info"][:, :6], base["info"][:, :6]), staged
 
 
 @pytest.mark.parametrize("waves,axis", [(3, 0), (2, -1), (4, 0)])

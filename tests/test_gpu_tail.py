@@ -92,8 +92,8 @@ def test_tail_handoff_on_the_general_member_and_in_small_or_other_launches():
     _same(res[1024], res[-1], "general member")
     assert (res[1024]["info"][:, 7] > 0).sum() > 0
     with nm.Handle(_cfg(lay, 40, tail_latency=200, staged=1)) as h:
-        h.solve(P[:1500])
-        assert h.last_launch_info()["tail_handed_off"] == 0         # B < 8 x the threshold
+        h.solve(P[:900])
+        assert h.last_launch_info()["tail_handed_off"] == 0         # B < 5 x the threshold
         h.solve(P[:4096].astype(np.float64), dtype=np.float64)
         assert h.last_launch_info()["tail_handed_off"] == 0         # fp64: no tail member
     with nm.Handle(_cfg(lay, 40, tail_latency=200, staged=-1)) as h:
