@@ -582,6 +582,9 @@ def secondary_workloads(env: Env, args) -> list:
              "closed loop (row f3), a third each from time steps %s" % (REFSCEN_STEPS,)),
             ("cfg2", "refscen", "f32", 2, 0, False, None, False, "budget"),
             ("cfg2", "refscen", "f32", 2, 0, False, None, True, None),
+            ("cfg2", "refscen", "f32", 5, 1, False, 6000, False,
+             "the same family at three device fills: what a closed-loop evaluation sends once most of its scenarios have finished "
+             "(resumable solve + tail hand-off from one fill on since round 6, profiles/r06_exp_mid_batches.txt)"),
             ("cfg2", "closed_loop", "f32", 2, 1, False, None, False,
              "round 5's builder-designed corridor family, harvested the same way at time steps %s" % (CLOSED_LOOP_STEPS,)),
             ("cfg2", "closed_loop", "f32", 2, 0, False, None, False, "budget"),
