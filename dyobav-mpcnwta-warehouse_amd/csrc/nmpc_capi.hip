@@ -958,8 +958,12 @@ Plan<T> plan_solve(nmpc_handle_s* h, int B, nmpc::KParams<T>& k)
     pl.fn = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs) : pick_solve<T>(h->lps, L.glb, L.rs);
     pl.has_axis = L.rs > 0 && h->lps == 3 && !L.glb;
     if (pl.has_axis) pl.fn2 = waves ? pick_solve_spec<T>(h->lps, L.glb, L.rs, 2) : pick_solve<T>(h->lps, L.glb, L.rs, 2);
-    // nmpc_config.batch_invariant: the latency plan on the TAIL members -- the throughput kernels' evaluation, hence their bits
-    if (waves && h->cfg.batch_invariant > 0)
+    // nmpc_config.batch_invariant: the latency plan on the TAIL members -- the throughput kernels' evaluation, hence their bits.
+    // Automatic (0): the 14-slot kernels. There the gated form is also the faster one on everything but the contract family
+    // (configs[2]'s dimensions, B = 1 .. 1 300: `passing` -8..-20 %, the reference scenarios -26..+1 %, the corridor family
+    // -18..+19 %, one instance alone -7..-17 % on all four families; the contract family -15..+20 % --
+    // profiles/r06_exp_mid_batches.txt); the 4- / 6-slot kernels keep the flat form configs[1] is quoted on.
+    if (waves && (h->cfg.batch_invariant > 0 || (h->cfg.batch_invariant == 0 && L.rs >= kRegSlotsLarge)))
         if (SolveFn<T> tf = pick_solve_tail<T>(h->lps, L.glb, L.rs, 1)) {
             pl.fn = tf;
             if (pl.has_axis) pl.fn2 = pick_solve_tail<T>(h->lps, L.glb, L.rs, 2);
@@ -1841,8 +1845,8 @@ int nmpc_create(const nmpc_config* cfg, nmpc_handle* out)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "max_solver_time_us < 0");
     if (cfg->max_evaluations < 0) return fail(NMPC_ERR_INVALID_ARGUMENT, "max_evaluations = %d < 0", cfg->max_evaluations);
     if (cfg->tail_latency < -1) return fail(NMPC_ERR_INVALID_ARGUMENT, "tail_latency = %d < -1", cfg->tail_latency);
-    if (cfg->batch_invariant != 0 && cfg->batch_invariant != 1)
-        return fail(NMPC_ERR_INVALID_ARGUMENT, "batch_invariant = %d (0 or 1)", cfg->batch_invariant);
+    if (cfg->batch_invariant < -1 || cfg->batch_invariant > 1)
+        return fail(NMPC_ERR_INVALID_ARGUMENT, "batch_invariant = %d (0 automatic, 1 always, -1 never)", cfg->batch_invariant);
     if (cfg->staged_evals < -1) return fail(NMPC_ERR_INVALID_ARGUMENT, "staged_evals = %d < -1", cfg->staged_evals);
     if (cfg->axis_aligned < -1 || cfg->axis_aligned > 1)
         return fail(NMPC_ERR_INVALID_ARGUMENT, "axis_aligned = %d (0 automatic, 1 promised, -1 never)", cfg->axis_aligned);
