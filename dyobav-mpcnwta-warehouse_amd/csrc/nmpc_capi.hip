@@ -1131,7 +1131,7 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
     // whatever long solves are still running -- one wavefront each, alone on its SIMD -- while the rest of the chip idles: on
     // batches with a skewed distribution of solve lengths the launch IS its longest instance
     // (profiles/r05_cfg2_passing_kernel_timeline.txt). The latency family's TAIL member (solve_spec_kernel<.., FLAT = false>:
-    // speculative line search over four wavefronts, the throughput kernels' own evaluation) computes the throughput kernels'
+    // speculative line search over six wavefronts, the throughput kernels' own evaluation) computes the throughput kernels'
     // bits and solves a long instance ~1.8x faster on an idle chip (tools/exp_tail_solo.py). So the LAST throughput launch
     // of a solve parks whatever is still running once it is in its drain phase -- every workgroup dispatched, at most
     // `park` instances left (KParams::dyn_ctr) -- at the instance's next outer-iteration boundary, and one more launch

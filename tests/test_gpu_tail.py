@@ -1,7 +1,7 @@
 """Tail hand-off (nmpc_config.tail_latency, round 6 / VERDICT r5 item 4): once the last throughput launch of a solve is in its
 drain phase -- every workgroup dispatched, at most `tail_latency` instances still running, each alone on its SIMD -- an
 instance parks at its next outer-iteration boundary and the latency family's TAIL member (the speculative line search over
-four wavefronts with the throughput kernels' own, gated evaluation) finishes it. The member returns the throughput kernels'
+six wavefronts with the throughput kernels' own, gated evaluation) finishes it. The member returns the throughput kernels'
 bits, so who solves which part of an instance is pure scheduling: every result array is identical with and without the
 hand-off, for any threshold, behind the pilot's ranking and under a caller's dispatch order, on both members of the kernel
 pairs, with an evaluation budget -- although WHICH instances are handed over depends on timing."""
