@@ -248,6 +248,7 @@ struct nmpc_handle_s {
     int axis_epoch = 0;
     DevBuf dresume, dorder2, dhist; // resumable solve: parked states, ranked order of the second launch, bucket counters
     DevBuf ddeep;                   // tail hand-off: solver states parked inside an inner solve (KParams::deep)
+    DevBuf dproxy;                  // dispatch order from one evaluation (run_solve): nominal controls, zeros, penalties, psi, ||F2||^2
     // polish: compact fp64 copies of the selected instances and their results
     DevBuf psel, pP, pU0, pY, pC, pU, pcost, pstatus, piters, pinfo;
     std::vector<int32_t> host_status, host_sel;
@@ -481,6 +482,29 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const T* resume, cons
         if (lane == leader) base = atomicAdd(&offs[0], __popcll(m0));
         base = __shfl(base, leader);
         order[base + __popcll(m0 & ((1ull << lane) - 1ull))] = b;
+    }
+}
+
+// Dispatch order of a latency-plan batch from ONE evaluation instead of a pilot launch (run_solve): the nominal controls
+// (v_nom, 0) at every step, zero multipliers, the initial penalty; and the key -- ||F2||^2 there -- written where rank_bucket
+// reads it (every instance counts as unfinished: nothing has been solved yet).
+template <typename T>
+__global__ __launch_bounds__(256) void proxy_fill_kernel(T* U, T* Y, T* C, int B, int n, T v_nom, T c_init)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)B * n) {
+        U[i] = (i & 1) ? T(0) : v_nom;
+        Y[i] = T(0);
+    }
+    if (i < (size_t)B) C[i] = c_init;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void proxy_key_kernel(const T* f2sq, T* resume, int* status, int B)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B) {
+        status[b] = -1;
+        resume[(size_t)b * nmpc::kResumeStride + 6 * 64 + 3] = f2sq[b];
     }
 }
 
@@ -1113,6 +1137,20 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
                                                    (int)(kLdsLimit / ((size_t)L.lds_total * sizeof(T))) * (h->n_simd / 4)));
     const int lat_cap = sizeof(T) == 4 ? h->n_simd : h->n_simd / 2;
     const bool reg32 = sizeof(T) == 4 && L.rs > 0 && !L.glb;
+    // Latency plan at about one workgroup per SIMD (configs[1]): the order decides which long solves share a SIMD to the end.
+    // Until round 6 a pilot launch ranked them (32.6 -> 28.5 ms then); the barrier and the second launch cost ~1.3 ms of
+    // 20, and an order from ONE evaluation -- ||F2||^2 at the nominal controls (2/3 v_max, 0), ~20 us -- does as well on the
+    // contract family below full oversubscription (B = 600 / 800: 21.5 -> 20.1 / 20.4 ms) and needs no barrier: `passing` -5..-7 %,
+    // the reference scenarios -6.5 %, configs[2]'s dimensions at 1 024: -2..-9 % (tools/exp_cfg1_proxy_order.py,
+    // profiles/r06_exp_proxy_order.txt; at 65 536 instances the pilot stays ahead).
+    // One measured exception keeps the pilot: the 4- / 6-slot kernels at full oversubscription (B > 7/8 of the SIMD count, four
+    // wavefronts per instance on three slots per SIMD -- configs[1] itself), where the order decides which quarter of the
+    // workgroups waits for a slot and the pilot's better key is worth its barrier on the contract family (21.1 against 21.6 ms;
+    // `passing` would gain 7 % there too: 20.6 -> 19.2).
+    const bool proxy = reg32 && pl.mode == 1 && caps[0] == 0 && allow_staging && pl.stageable && !k.order && k.status &&
+                       B > lat_cap / 2 && B <= lat_cap && (L.rs >= kRegSlotsLarge || 8 * B <= 7 * lat_cap) &&
+                       dev_factor("NMPC_PROXY_ORDER", 1) > 0;
+    if (proxy) caps[0] = -1;
     if (caps[0] == 0)
         caps[0] = ((pl.mode == 0 && B >= dev_factor("NMPC_STAGE_FILLS", !reg32 ? kStageFills : L.rs >= kRegSlotsLarge ? kFillsLarge : kStageFillsReg) * (pl.resident ? pl.resident : resident)) || (pl.mode == 1 && B > lat_cap / 2 && B <= lat_cap) ||
                    (pl.mode == 2 && !pl.uses_ws && B >= 4 * pl.resident)) ? 1 : -1; // (configs[4] fp32: 2 116 -> 2 087 ms;
@@ -1148,6 +1186,33 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
     const bool big = B >= dev_factor("NMPC_TAIL_FILLS", !reg32 ? kTailFills : L.rs >= kRegSlotsLarge ? kFillsLarge : kTailFillsReg) * (pl.resident ? pl.resident : resident);
     const Plan<T> tail = (park > 0 && allow_staging && k.status && pl.stageable && (n_stage > 0 || (k.order && big)) && B >= dev_factor("NMPC_TAIL_MINB", kTailMinParks) * park)
                              ? plan_tail<T>(h, pl, L, tail_waves) : Plan<T>();
+    if (proxy && n_stage == 0 && !tail.fn) {
+        const size_t n = 2 * (size_t)h->cfg.N_hor;
+        if (int rc = h->dresume.reserve((size_t)B * nmpc::kResumeStride * sizeof(T))) return rc;
+        if (int rc = h->dorder2.reserve((size_t)B * sizeof(int))) return rc;
+        if (int rc = h->dproxy.reserve((2 * (size_t)B * n + 3 * (size_t)B) * sizeof(T))) return rc;
+        T* const Un = static_cast<T*>(h->dproxy.p);
+        nmpc::EvalParams<T> ep;
+        ep.U = Un, ep.Y = Un + (size_t)B * n, ep.C = Un + 2 * (size_t)B * n;
+        ep.psi = Un + 2 * (size_t)B * n + B, ep.grad = nullptr, ep.f2sq = Un + 2 * (size_t)B * n + 2 * (size_t)B;
+        const int nbf = (int)(((size_t)B * n + 255) / 256), nb = (B + 255) / 256;
+        hipLaunchKernelGGL(proxy_fill_kernel<T>, dim3(nbf), dim3(256), 0, h->stream, Un, Un + (size_t)B * n, Un + 2 * (size_t)B * n, B, (int)n,
+                           T(dev_factor("NMPC_PROXY_VNOM", 2.0 / 3.0)) * k.vmax, k.c_init);
+        const size_t lds_eval = (size_t)L.lds_total * sizeof(T);
+        if (k.axis_mode != 0) hipLaunchKernelGGL(pick_eval<T>(h->lps, L.glb, L.rs, 1), dim3(B), dim3(64), lds_eval, h->stream, k, ep);
+        if (k.axis_mode != 1) hipLaunchKernelGGL(pick_eval<T>(h->lps, L.glb, L.rs, 2), dim3(B), dim3(64), lds_eval, h->stream, k, ep);
+        T* const resume = static_cast<T*>(h->dresume.p);
+        int* const hist = static_cast<int*>(h->dhist.p);
+        int* const order2 = static_cast<int*>(h->dorder2.p);
+        hipLaunchKernelGGL(proxy_key_kernel<T>, dim3(nb), dim3(256), 0, h->stream, ep.f2sq, resume, k.status, B);
+        hipLaunchKernelGGL(rank_hist_kernel<T>, dim3(nb), dim3(256), 0, h->stream, resume, k.status, B, hist, 0);
+        hipLaunchKernelGGL(rank_scan_kernel, dim3(1), dim3(kRankBuckets), 0, h->stream, hist, hist + kRankBuckets, (int*)nullptr);
+        hipLaunchKernelGGL(rank_scatter_kernel<T>, dim3(nb), dim3(256), 0, h->stream, resume, k.status, B, hist + kRankBuckets, order2, 0);
+        HIP_TRY(hipGetLastError());
+        nmpc::KParams<T> ki = k;
+        ki.order = order2;
+        return launch_plan<T>(h, pl, ki, B);
+    }
     if (n_stage == 0 && !tail.fn) return launch_plan<T>(h, pl, k, B);
     if (tail.fn) {
         if (int rc = h->ddeep.reserve((size_t)park * nmpc::deep_park_stride(h->cfg.N_hor) * sizeof(T))) return rc;

@@ -158,3 +158,31 @@ def test_latency_kernel_follows_the_throughput_kernel_step_for_step():
     d = np.abs(a["U"] - b["U"]).max(axis=1)[conv]
     print("tolerance 1e-8, converged on both:", conv.sum(), "median", np.median(d), "q90", np.quantile(d, 0.9))
     assert conv.sum() >= 30 and np.median(d) < 1e-7 and np.quantile(d, 0.8) < 1e-4
+
+
+def test_latency_plans_get_their_dispatch_order_from_one_evaluation():
+    """Round 6: at about one workgroup per SIMD (512 < B <= 1 024) the order decides which long solves share a SIMD to the end. A
+    pilot launch used to rank the instances; one evaluation at nominal controls -- ||F2||^2 at (2/3 v_max, 0) -- does it without
+    the barrier (the 4- / 6-slot kernels above 896 instances keep the pilot: configs[1] itself). Whatever the order and the number
+    of launches, the results are the same bits."""
+    lay = nm.scenarios.ParamLayout(20, 10, 10, 15)
+    for B, staged_expected in ((700, 0), (1000, 1)):
+        P = nm.scenarios.make_batch_chunked(B, lay, seed=71, n_ped=2, n_hyp=5, dtype=np.float32)
+        res = {}
+        for staged in (0, -1, 1):
+            cfg = nm.default_config_struct()
+            cfg.max_active_dynobs, cfg.staged = 10, staged
+            with nm.Handle(cfg) as h:
+                res[staged] = h.solve(P)
+                li = h.last_launch_info()
+            assert li["family"] == "latency" and li["staged_outer_iterations"] == (staged_expected if staged == 0 else max(staged, 0)), (B, staged, li)
+        for k in ("U", "y", "cost", "status", "iters"):
+            assert np.array_equal(res[0][k], res[-1][k]) and np.array_equal(res[0][k], res[1][k]), (B, k)
+    # 14-slot kernels: no exception
+    lay2 = nm.scenarios.ParamLayout(20, 10, 10, 40)
+    cfg = nm.default_config_struct()
+    cfg.Ndynobs, cfg.max_active_dynobs = 40, 40
+    with nm.Handle(cfg) as h:
+        r = h.solve(nm.scenarios.make_batch_chunked(1000, lay2, seed=72, n_ped=4, n_hyp=10, dtype=np.float32))
+        assert h.last_launch_info()["family"] == "latency" and h.last_launch_info()["staged_outer_iterations"] == 0
+        assert (r["status"] >= 0).all()

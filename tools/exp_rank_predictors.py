@@ -7,7 +7,7 @@ REMAINING evaluations are then list-scheduled on the device's wavefront slots (g
 the slot that frees first) under different orders -- index order, the shipped key (top 10 bits of ||F2||), candidates, and
 the true remaining work (LPT) -- and the makespan is reported in evaluations and against the bound max(sum / slots, longest).
 The features and targets are saved to gpurun_out/rank_features_<family>.npz for fitting off the box.
-   usage: exp_rank_predictors.py [passing|refscen|corridor ...]   env: B (65536), SLOTS (2048)"""
+   usage: exp_rank_predictors.py [passing|refscen|corridor ...]   env: B (65536), SLOTS (2048), DIMS=cfg1|cfg2"""
 import heapq, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,15 +15,15 @@ import numpy as np
 import dyobav_mpcnwta_warehouse_amd as nm
 
 B = int(os.environ.get("B", "65536")); SLOTS = int(os.environ.get("SLOTS", "2048"))
-key = "cfg2_b65536_n20_4x10"
+key = {"cfg1": "cfg1_b1024_n20_2x5", "cfg2": "cfg2_b65536_n20_4x10"}[os.environ.get("DIMS", "cfg2")]
 spec = dict(nm.scenarios.BENCH_CONFIGS[key]); lay = spec.pop("layout"); spec.pop("B")
 
 
 def batch(fam):
     if fam in ("refscen", "corridor"):
-        cfg = nm.default_config_struct(); cfg.Ndynobs, cfg.max_active_dynobs = lay.Ndyn, 40
+        cfg = nm.default_config_struct(); cfg.Ndynobs, cfg.max_active_dynobs = lay.Ndyn, spec['n_ped'] * spec['n_hyp']
         steps, hf = ((2, 14, 26), "reference") if fam == "refscen" else ((1, 8, 20), "corridor")
-        P, _ = nm.scenarios.harvest_closed_loop(cfg, B, steps=steps, seed=13, n_ped=4, n_hyp=10, dtype=np.float32, family=hf)
+        P, _ = nm.scenarios.harvest_closed_loop(cfg, B, steps=steps, seed=13, n_ped=spec['n_ped'], n_hyp=spec['n_hyp'], dtype=np.float32, family=hf)
         return np.ascontiguousarray(P, np.float32)
     return np.ascontiguousarray(nm.scenarios.make_batch_chunked(B, lay, ped_mode=fam, dtype=np.float32, **spec), np.float32)
 
@@ -31,7 +31,7 @@ def batch(fam):
 def solve(P, **ov):
     cfg = nm.default_config_struct()
     cfg.N_hor, cfg.Nother, cfg.Nstcobs, cfg.Ndynobs = lay.N, lay.Nother, lay.Nstc, lay.Ndyn
-    cfg.max_active_dynobs = 40
+    cfg.max_active_dynobs = spec['n_ped'] * spec['n_hyp']
     for k, v in ov.items():
         setattr(cfg, k, v)
     n = P.shape[0]
