@@ -1147,8 +1147,11 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
     // wavefronts per instance on three slots per SIMD -- configs[1] itself), where the order decides which quarter of the
     // workgroups waits for a slot and the pilot's better key is worth its barrier on the contract family (21.1 against 21.6 ms;
     // `passing` would gain 7 % there too: 20.6 -> 19.2).
+    // The two-wavefront plans of the 4- / 6-slot kernels (1 024 < B <= 4 096, up to 2.7x oversubscribed) had no ranking at all: the
+    // same evaluation order there -- B = 2 500 / 4 096: contract family -10 / -12 %, corridor -9 %, `passing` -4 / -6 %, the
+    // reference scenarios +-2 %; a pilot launch loses or ties everywhere (same record). 14-slot kernels, 769..1 433: neutral, none.
     const bool proxy = reg32 && pl.mode == 1 && caps[0] == 0 && allow_staging && pl.stageable && !k.order && k.status &&
-                       B > lat_cap / 2 && B <= lat_cap && (L.rs >= kRegSlotsLarge || 8 * B <= 7 * lat_cap) &&
+                       B > lat_cap / 2 && (B <= lat_cap ? (L.rs >= kRegSlotsLarge || 8 * B <= 7 * lat_cap) : (L.rs < kRegSlotsLarge && B <= 4 * lat_cap)) &&
                        dev_factor("NMPC_PROXY_ORDER", 1) > 0;
     if (proxy) caps[0] = -1;
     if (caps[0] == 0)

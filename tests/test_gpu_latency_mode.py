@@ -178,6 +178,16 @@ def test_latency_plans_get_their_dispatch_order_from_one_evaluation():
             assert li["family"] == "latency" and li["staged_outer_iterations"] == (staged_expected if staged == 0 else max(staged, 0)), (B, staged, li)
         for k in ("U", "y", "cost", "status", "iters"):
             assert np.array_equal(res[0][k], res[-1][k]) and np.array_equal(res[0][k], res[1][k]), (B, k)
+    # the two-wavefront plans of the 4- / 6-slot kernels (1 024 < B <= 4 096) are ordered the same way; bits as under any order
+    P = nm.scenarios.make_batch_chunked(2500, lay, seed=73, n_ped=2, n_hyp=5, dtype=np.float32)
+    res = {}
+    for staged in (0, -1):
+        cfg = nm.default_config_struct()
+        cfg.max_active_dynobs, cfg.staged = 10, staged
+        with nm.Handle(cfg) as h:
+            res[staged] = h.solve(P)
+            assert h.last_launch_info()["family"] == "latency" and h.last_launch_info()["staged_outer_iterations"] == 0
+    assert np.array_equal(res[0]["U"], res[-1]["U"]) and np.array_equal(res[0]["iters"], res[-1]["iters"])
     # 14-slot kernels: no exception
     lay2 = nm.scenarios.ParamLayout(20, 10, 10, 40)
     cfg = nm.default_config_struct()

@@ -3,7 +3,7 @@
 evaluation sends once most of its scenarios have finished. The resumable solve (pilot + ranking) and the tail hand-off are
 switched on from four fills on; does either pay below? Needs a development build (-DNMPC_DEV_ENV: thresholds from the
 environment, in device fills), e.g. build/libnmpc_devenv.so through NMPC_HIP_LIBRARY.
-   usage: exp_mid_batches.py [family ...]      one JSON line per (family, B, order, thresholds)   env: SIZES, FILLS (stage/tail,...), LW, DIMS=cfg1|cfg2, BI (batch_invariant), TAIL (tail_latency)"""
+   usage: exp_mid_batches.py [family ...]      one JSON line per (family, B, order, thresholds)   env: SIZES, FILLS (stage/tail,...), LW, DIMS=cfg1|cfg2, BI (batch_invariant), TAIL (tail_latency), STAGED (staged)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CODE = r'''
@@ -27,6 +27,7 @@ cfg.axis_aligned = 1
 cfg.latency_waves = int(os.environ.get("LW", "0"))
 cfg.batch_invariant = int(os.environ.get("BI", "0"))
 cfg.tail_latency = int(os.environ.get("TAIL", "0"))
+cfg.staged = int(os.environ.get("STAGED", "0"))
 U = np.empty((B, 2 * lay.N), np.float32); st = np.empty(B, np.int32); info = np.empty((B, 8), np.float32)
 with nm.Handle(cfg) as h:
     h.solve_raw(np.float32, P, B, U, status=st, info=info)
