@@ -893,6 +893,7 @@ constexpr double kStageFills = 4, kTailFills = 4, kStageFillsReg = 1, kTailFills
 // 27.2 ms, reference scenarios 31.0 -> 32.5, contract family 62.2 -> 50.5; at 1 024 the contract family still loses 20 % to two
 // wavefronts per instance, and at configs[1]'s dimensions (4-slot kernels) it does so up to a full fill (same record).
 constexpr double kFillsLarge = 0.7;
+constexpr double kProxyFills = 8;     // throughput plans below this many fills: dispatch order from one evaluation instead of a pilot launch
 constexpr double kTailMinParks = 5;   // the hand-off needs a batch of at least this many parking thresholds (8 until the above)
 
 template <typename T>
@@ -1150,9 +1151,16 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
     // The two-wavefront plans of the 4- / 6-slot kernels (1 024 < B <= 4 096, up to 2.7x oversubscribed) had no ranking at all: the
     // same evaluation order there -- B = 2 500 / 4 096: contract family -10 / -12 %, corridor -9 %, `passing` -4 / -6 %, the
     // reference scenarios +-2 %; a pilot launch loses or ties everywhere (same record). 14-slot kernels, 769..1 433: neutral, none.
-    const bool proxy = reg32 && pl.mode == 1 && caps[0] == 0 && allow_staging && pl.stageable && !k.order && k.status &&
-                       B > lat_cap / 2 && (B <= lat_cap ? (L.rs >= kRegSlotsLarge || 8 * B <= 7 * lat_cap) : (L.rs < kRegSlotsLarge && B <= 4 * lat_cap)) &&
-                       dev_factor("NMPC_PROXY_ORDER", 1) > 0;
+    const double fills_ = !reg32 ? kStageFills : L.rs >= kRegSlotsLarge ? kFillsLarge : kStageFillsReg;
+    const int res_ = pl.resident ? pl.resident : resident;
+    // ... and the throughput plans up to eight device fills (tools/exp_cfg1_proxy_order.py at 3 000 .. 40 000 instances, both
+    // dimensions, same record): one launch in the evaluation order + the tail hand-off against pilot + ranking + hand-off --
+    // `passing` / the reference scenarios -8..-11 % up to six fills, the contract family -3..+1 %; level at eight fills; from ten
+    // on the pilot's key wins (65 536: `passing` 85.7 against 91.3 ms) and stays.
+    const bool proxy = reg32 && caps[0] == 0 && allow_staging && pl.stageable && !k.order && k.status && dev_factor("NMPC_PROXY_ORDER", 1) > 0 &&
+                       (pl.mode == 1 ? (B > lat_cap / 2 && (B <= lat_cap ? (L.rs >= kRegSlotsLarge || 8 * B <= 7 * lat_cap)
+                                                                         : (L.rs < kRegSlotsLarge && B <= 4 * lat_cap)))
+                                     : (pl.mode == 0 && B >= fills_ * res_ && B < dev_factor("NMPC_PROXY_FILLS", kProxyFills) * res_));
     if (proxy) caps[0] = -1;
     if (caps[0] == 0)
         caps[0] = ((pl.mode == 0 && B >= dev_factor("NMPC_STAGE_FILLS", !reg32 ? kStageFills : L.rs >= kRegSlotsLarge ? kFillsLarge : kStageFillsReg) * (pl.resident ? pl.resident : resident)) || (pl.mode == 1 && B > lat_cap / 2 && B <= lat_cap) ||
@@ -1168,28 +1176,14 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
             ++n_stage;
         }
     h->last_staged = n_stage == 0 ? 0 : n_stage == 1 ? stage_cap[0] : 100 * stage_cap[0] + stage_cap[1];
-    // Tail hand-off (nmpc_config.tail_latency; round 6, VERDICT r5 item 4). A launch of the throughput kernel ends with
-    // whatever long solves are still running -- one wavefront each, alone on its SIMD -- while the rest of the chip idles: on
-    // batches with a skewed distribution of solve lengths the launch IS its longest instance
-    // (profiles/r05_cfg2_passing_kernel_timeline.txt). The latency family's TAIL member (solve_spec_kernel<.., FLAT = false>:
-    // speculative line search over six wavefronts, the throughput kernels' own evaluation) computes the throughput kernels'
-    // bits and solves a long instance ~1.8x faster on an idle chip (tools/exp_tail_solo.py). So the LAST throughput launch
-    // of a solve parks whatever is still running once it is in its drain phase -- every workgroup dispatched, at most
-    // `park` instances left (KParams::dyn_ctr) -- at the instance's next outer-iteration boundary, and one more launch
-    // -- the tail member over the parked instances, found by the same ranking kernels -- finishes them. Who solves which
-    // part of an instance depends on timing; the results do not (tests/test_gpu_tail.py). (Running the two families side by
-    // side on two streams does not work: with tens of thousands of one-wavefront workgroups pending, a four-wavefront
-    // workgroup never finds its four slots on one CU and runs after the throughput launch -- profiles/r06_ab_tail_handoff.jsonl.)
     h->last_tail = 0;
-    int park = h->cfg.tail_latency;
-    if (park == 0) park = std::max(32, h->n_simd / 4);      // automatic: one tail workgroup per CU
-    // (six wavefronts per parked instance while they are all resident at two per SIMD, else four: `passing` 87.0 -> 84.4 ms per
-    //  call, batches of 3 000 / 6 000: -8 / -6 %; eight bring nothing more -- profiles/r06_exp_mid_batches.txt)
-    const int tail_waves = (int)dev_factor("NMPC_TAIL_WAVES", park * kSpecWavesWide <= 2 * h->n_simd ? kSpecWavesWide : kSpecWaves);
-    const bool big = B >= dev_factor("NMPC_TAIL_FILLS", !reg32 ? kTailFills : L.rs >= kRegSlotsLarge ? kFillsLarge : kTailFillsReg) * (pl.resident ? pl.resident : resident);
-    const Plan<T> tail = (park > 0 && allow_staging && k.status && pl.stageable && (n_stage > 0 || (k.order && big)) && B >= dev_factor("NMPC_TAIL_MINB", kTailMinParks) * park)
-                             ? plan_tail<T>(h, pl, L, tail_waves) : Plan<T>();
-    if (proxy && n_stage == 0 && !tail.fn) {
+    // (the evaluation order below goes into k.order for the rest of this function only: the caller's k gets its own back)
+    struct OrderGuard {
+        nmpc::KParams<T>& kk;
+        decltype(nmpc::KParams<T>::order) saved;
+        ~OrderGuard() { kk.order = saved; }
+    } order_guard{k, k.order};
+    if (proxy) {
         const size_t n = 2 * (size_t)h->cfg.N_hor;
         if (int rc = h->dresume.reserve((size_t)B * nmpc::kResumeStride * sizeof(T))) return rc;
         if (int rc = h->dorder2.reserve((size_t)B * sizeof(int))) return rc;
@@ -1212,10 +1206,30 @@ int run_solve(nmpc_handle_s* h, nmpc::KParams<T>& k, int B, bool allow_staging)
         hipLaunchKernelGGL(rank_scan_kernel, dim3(1), dim3(kRankBuckets), 0, h->stream, hist, hist + kRankBuckets, (int*)nullptr);
         hipLaunchKernelGGL(rank_scatter_kernel<T>, dim3(nb), dim3(256), 0, h->stream, resume, k.status, B, hist + kRankBuckets, order2, 0);
         HIP_TRY(hipGetLastError());
-        nmpc::KParams<T> ki = k;
-        ki.order = order2;
-        return launch_plan<T>(h, pl, ki, B);
+        k.order = order2;   // (from here on as under a caller's order: one launch, the tail hand-off where the batch is big enough)
+        if (pl.mode == 1) return launch_plan<T>(h, pl, k, B);
     }
+    // Tail hand-off (nmpc_config.tail_latency; round 6, VERDICT r5 item 4). A launch of the throughput kernel ends with
+    // whatever long solves are still running -- one wavefront each, alone on its SIMD -- while the rest of the chip idles: on
+    // batches with a skewed distribution of solve lengths the launch IS its longest instance
+    // (profiles/r05_cfg2_passing_kernel_timeline.txt). The latency family's TAIL member (solve_spec_kernel<.., FLAT = false>:
+    // speculative line search over six wavefronts, the throughput kernels' own evaluation) computes the throughput kernels'
+    // bits and solves a long instance ~1.8x faster on an idle chip (tools/exp_tail_solo.py). So the LAST throughput launch
+    // of a solve parks whatever is still running once it is in its drain phase -- every workgroup dispatched, at most
+    // `park` instances left (KParams::dyn_ctr) -- at the instance's next outer-iteration boundary, and one more launch
+    // -- the tail member over the parked instances, found by the same ranking kernels -- finishes them. Who solves which
+    // part of an instance depends on timing; the results do not (tests/test_gpu_tail.py). (Running the two families side by
+    // side on two streams does not work: with tens of thousands of one-wavefront workgroups pending, a four-wavefront
+    // workgroup never finds its four slots on one CU and runs after the throughput launch -- profiles/r06_ab_tail_handoff.jsonl.)
+    h->last_tail = 0;
+    int park = h->cfg.tail_latency;
+    if (park == 0) park = std::max(32, h->n_simd / 4);      // automatic: one tail workgroup per CU
+    // (six wavefronts per parked instance while they are all resident at two per SIMD, else four: `passing` 87.0 -> 84.4 ms per
+    //  call, batches of 3 000 / 6 000: -8 / -6 %; eight bring nothing more -- profiles/r06_exp_mid_batches.txt)
+    const int tail_waves = (int)dev_factor("NMPC_TAIL_WAVES", park * kSpecWavesWide <= 2 * h->n_simd ? kSpecWavesWide : kSpecWaves);
+    const bool big = B >= dev_factor("NMPC_TAIL_FILLS", !reg32 ? kTailFills : L.rs >= kRegSlotsLarge ? kFillsLarge : kTailFillsReg) * (pl.resident ? pl.resident : resident);
+    const Plan<T> tail = (park > 0 && allow_staging && k.status && pl.stageable && (n_stage > 0 || (k.order && big)) && B >= dev_factor("NMPC_TAIL_MINB", kTailMinParks) * park)
+                             ? plan_tail<T>(h, pl, L, tail_waves) : Plan<T>();
     if (n_stage == 0 && !tail.fn) return launch_plan<T>(h, pl, k, B);
     if (tail.fn) {
         if (int rc = h->ddeep.reserve((size_t)park * nmpc::deep_park_stride(h->cfg.N_hor) * sizeof(T))) return rc;
